@@ -1,0 +1,231 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference on disk; the reference
+never travels to the GPU box):
+
+    python -m oracle.make_goldens
+
+For every case it (1) builds the reference ``SuperResolutionNet`` / ``EWC``
+(imported from /root/reference, nothing copied), loads the formula weights of
+``oracle.synth``, runs forward + backward on formula inputs, (2) runs the oracle
+restatement on the same data and asserts agreement, (3) stores the reference's
+numbers.  Fixtures hold data only: outputs, selected intermediates, per-tensor
+gradient summaries, BN running statistics, loss trajectories, EWC quantities.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("NVQ_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, REPO)
+from oracle import sr_oracle, synth  # noqa: E402
+
+CASES = {
+    # name: (F, N, window, scale, B, H, W, train)
+    "a_f32n2_t3_s2_train": (32, 2, 1, 2, 2, 12, 16, True),
+    "b_f16n1_t5_s4_train": (16, 1, 2, 4, 1, 10, 12, True),
+    "c_f32n1_t3_s3_eval": (32, 1, 1, 3, 1, 9, 11, False),
+    "d_f64n1_t3_s2_train": (64, 1, 1, 2, 1, 8, 40, True),
+}
+SAMPLE_IDX = 16
+GAIN = synth.GOLDEN_GAIN
+
+
+def grad_summary(g: torch.Tensor) -> np.ndarray:
+    """[sum, l2, 16 strided samples] of a gradient tensor, float64."""
+    flat = g.detach().double().reshape(-1)
+    n = flat.numel()
+    idx = (np.arange(SAMPLE_IDX) * max(n // SAMPLE_IDX, 1)) % n
+    return np.concatenate([[flat.sum().item(), flat.norm().item()], flat[idx].numpy()])
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import nerve_cl  # noqa: F401  (the reference package)
+    from nerve_cl.models import SuperResolutionNet
+    from nerve_cl.continual import EWC
+    assert os.path.abspath(nerve_cl.__file__).startswith(os.path.abspath(REF)), nerve_cl.__file__
+    return SuperResolutionNet, EWC
+
+
+def run_case(name, cfg, RefSR):
+    Fc, N, win, s, B, H, W, train = cfg
+    T = 2 * win + 1
+    sd = synth.formula_state(3, s, Fc, N, win, gain=GAIN)
+    x = synth.formula_clip(B, T, H, W)
+    tgt = synth.formula_target(B, H * s, W * s)
+
+    ref = RefSR(3, s, Fc, N, win)
+    ref.load_state_dict(sd, strict=True)
+    ref.train(train)
+    out, inter = ref(x, return_intermediate=True)
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+
+    ora = sr_oracle.OracleSR(3, s, Fc, N, win)
+    ora.load_named(sd)
+    ora.train(train)
+    o_out, o_inter = ora(x, return_intermediate=True)
+    o_loss = F.mse_loss(o_out, tgt)
+    o_loss.backward()
+
+    # oracle vs reference, at generation time
+    def close(a, b, what, tol=2e-5):
+        a, b = a.detach().double(), b.detach().double()
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err <= tol, f"{name}: oracle != reference for {what}: rel {err:.3e}"
+        return err
+    worst = close(o_out, out, "output")
+    for t in range(T):
+        worst = max(worst, close(o_inter["features"][t], inter["features"][t], f"features[{t}]"))
+        worst = max(worst, close(o_inter["aligned"][t], inter["aligned"][t], f"aligned[{t}]"))
+    worst = max(worst, close(o_inter["aggregated"], inter["aggregated"], "aggregated"))
+    ref_named = dict(ref.named_parameters())
+    for n, p in ora.named().items():
+        if n in ref_named:
+            worst = max(worst, close(p.grad, ref_named[n].grad, "grad " + n, tol=1e-4))
+    ref_sd = ref.state_dict()
+    for n in sr_oracle.buffer_shapes(Fc):
+        worst = max(worst, close(ora.named()[n].double(), ref_sd[n].double(), "buffer " + n))
+
+    blob = {
+        "cfg": np.array([Fc, N, win, s, B, H, W, int(train)], dtype=np.int64),
+        "output": out.detach().numpy(),
+        "loss": np.array(loss.item(), dtype=np.float64),
+        "feat0": inter["features"][0].detach().numpy(),
+        "aligned0": inter["aligned"][0].detach().numpy(),
+        "aggregated": inter["aggregated"].detach().numpy(),
+        "clamped_frac": np.array(((out == 0) | (out == 1)).float().mean().item()),
+    }
+    for n, p in ref.named_parameters():
+        g = p.grad
+        blob["gsum/" + n] = grad_summary(g)
+        if g.numel() <= 256:
+            blob["gfull/" + n] = g.detach().numpy()
+    for n in sr_oracle.buffer_shapes(Fc):
+        blob["buf/" + n] = ref_sd[n].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, f"sr_{name}.npz"), **blob)
+    print(f"{name}: loss {loss.item():.6f} clamped {blob['clamped_frac']:.3f} "
+          f"oracle-vs-ref worst rel {worst:.2e}")
+
+
+def run_trajectory(RefSR):
+    """Three train_baseline-style steps (experiments/train_baseline.py:51-64,79-88):
+    F=32, N=4, AdamW(lr=1e-3, wd=1e-5), MSE, input expanded to T=3 identical frames."""
+    Fc, N, win, s, B, H, W = 32, 4, 1, 2, 2, 16, 16
+    sd = synth.formula_state(3, s, Fc, N, win, gain=GAIN)
+    lr = synth.formula_clip(B, 1, H, W, seed=5)[:, 0]
+    hr = synth.formula_target(B, H * s, W * s, seed=7)
+
+    def drive(model, steps=3):
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        losses = []
+        model.train()
+        for _ in range(steps):
+            opt.zero_grad()
+            out = model(lr.unsqueeze(1).expand(-1, 3, -1, -1, -1))
+            loss = F.mse_loss(out, hr)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        model.eval()
+        with torch.no_grad():
+            out = model(lr.unsqueeze(1).expand(-1, 3, -1, -1, -1))
+        return np.array(losses), out.numpy(), sr_oracle.compute_psnr(out, hr)
+
+    ref = RefSR(3, s, Fc, N, win)
+    ref.load_state_dict(sd)
+    rl, rout, rpsnr = drive(ref)
+    ora = sr_oracle.OracleSR(3, s, Fc, N, win)
+    ora.load_named(sd)
+    ol, oout, opsnr = drive(ora)
+    assert np.allclose(rl, ol, rtol=1e-5), (rl, ol)
+    assert np.abs(rout - oout).max() < 1e-4
+    np.savez_compressed(os.path.join(OUT, "traj_baseline.npz"),
+                        cfg=np.array([Fc, N, win, s, B, H, W]), losses=rl,
+                        eval_output=rout, psnr=np.array(rpsnr))
+    print("trajectory losses", rl, "psnr", rpsnr)
+
+
+def run_ewc(RefSR, RefEWC):
+    """EWC on the bare SR net through the 4-D -> 5-D adapter of SURVEY.md 3.4:
+    two tasks, loader batch 2, lambda 5000, online mode decay 0.999."""
+    Fc, N, win, s, H, W = 32, 1, 1, 2, 8, 8
+
+    class Adapter(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return self.net(x.unsqueeze(1).expand(-1, 3, -1, -1, -1))
+
+    sd = synth.formula_state(3, s, Fc, N, win, gain=GAIN)
+    tasks = []
+    for k in range(2):
+        lr = synth.formula_clip(4, 1, H, W, seed=31 + k)[:, 0]
+        hr = synth.formula_target(4, H * s, W * s, seed=41 + k)
+        tasks.append([(lr[0:2], hr[0:2]), (lr[2:4], hr[2:4])])
+
+    ref = Adapter(RefSR(3, s, Fc, N, win))
+    ref.net.load_state_dict(sd)
+    ewc = RefEWC(ref, ewc_lambda=5000.0)
+    ora = Adapter(sr_oracle.OracleSR(3, s, Fc, N, win))
+    ora.net.load_named(sd)
+    o_named = [("net." + n, p) for n, p in ora.net.named().items() if p.requires_grad]
+
+    blob = {"cfg": np.array([Fc, N, win, s, 4, H, W])}
+    o_fisher, o_opt = None, None
+    for k, batches in enumerate(tasks):
+        ewc.register_task(k, batches)
+        f_new = sr_oracle.ewc_fisher(ora, batches, o_named)
+        o_fisher = sr_oracle.ewc_online_merge(o_fisher, f_new)
+        o_opt = {n: p.detach().clone() for n, p in o_named}
+        for n, p in o_named:
+            a, b = o_fisher[n].double(), ewc.fisher_dict[n].double()
+            err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            assert err < 2e-5, (n, err)
+        # perturb the weights deterministically (stands in for training on the next task)
+        with torch.no_grad():
+            for (n, p), (_, q) in zip(ref.named_parameters(), o_named):
+                d = torch.from_numpy((synth.hash01(p.numel(), synth.name_seed(n) + k + 1)
+                                      .reshape(p.shape) * 2 - 1).astype(np.float32)) * 0.01
+                p.add_(d)
+                q.add_(d)
+        ref.zero_grad()
+        pen = ewc.penalty()
+        pen.backward()
+        o_pen = sr_oracle.ewc_penalty(o_named, o_fisher, o_opt, 5000.0)
+        assert abs(o_pen.item() - pen.item()) <= 1e-5 * abs(pen.item()), (o_pen.item(), pen.item())
+        blob[f"penalty{k}"] = np.array(pen.item(), dtype=np.float64)
+        for n, p in ref.named_parameters():
+            key = n[len("net."):]
+            blob[f"fisher{k}/{key}"] = grad_summary(ewc.fisher_dict[n])
+            blob[f"pgrad{k}/{key}"] = grad_summary(p.grad)
+    np.savez_compressed(os.path.join(OUT, "ewc_two_tasks.npz"), **blob)
+    print("ewc penalties", blob["penalty0"], blob["penalty1"])
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    RefSR, RefEWC = import_reference()
+    for name, cfg in CASES.items():
+        run_case(name, cfg, RefSR)
+    run_trajectory(RefSR)
+    run_ewc(RefSR, RefEWC)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"wrote {OUT}: {total/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""CPU: the oracle restatement against the fixtures captured from the reference
+(tests/golden, written by oracle/make_goldens.py).  This is what pins the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sr_oracle, synth
+from oracle.make_goldens import grad_summary
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sr_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 4
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[3:-4] for p in CASES])
+def test_forward_backward_matches_reference_fixture(path):
+    g = np.load(path)
+    Fc, N, win, s, B, H, W, train = [int(v) for v in g["cfg"]]
+    T = 2 * win + 1
+    sd = synth.formula_state(3, s, Fc, N, win, gain=synth.GOLDEN_GAIN)
+    x = synth.formula_clip(B, T, H, W)
+    tgt = synth.formula_target(B, H * s, W * s)
+    m = sr_oracle.OracleSR(3, s, Fc, N, win)
+    m.load_named(sd)
+    m.train(bool(train))
+    out, inter = m(x, return_intermediate=True)
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+    assert out.shape == (B, 3, H * s, W * s)
+    assert _rel(out.detach().numpy(), g["output"]) < 1e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert _rel(inter["features"][0].detach().numpy(), g["feat0"]) < 1e-5
+    assert _rel(inter["aligned"][0].detach().numpy(), g["aligned0"]) < 2e-5
+    assert _rel(inter["aggregated"].detach().numpy(), g["aggregated"]) < 2e-5
+    named = m.named()
+    for key in g.files:
+        if key.startswith("gsum/"):
+            n = key[5:]
+            ref = g[key]
+            got = grad_summary(named[n].grad)
+            # l2 norm to 1e-4 rel, samples relative to the tensor's max sample
+            assert abs(got[1] - ref[1]) <= 1e-4 * max(ref[1], 1e-12), n
+            assert np.abs(got[2:] - ref[2:]).max() <= 1e-4 * max(np.abs(ref[2:]).max(), ref[1] * 1e-2), n
+        elif key.startswith("gfull/"):
+            n = key[6:]
+            assert _rel(named[n].grad.numpy(), g[key]) < 1e-4, n
+        elif key.startswith("buf/"):
+            n = key[4:]
+            assert _rel(named[n].double().numpy(), g[key]) < 1e-5, n
+
+
+def test_baseline_trajectory():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "traj_baseline.npz"))
+    Fc, N, win, s, B, H, W = [int(v) for v in g["cfg"]]
+    sd = synth.formula_state(3, s, Fc, N, win, gain=synth.GOLDEN_GAIN)
+    lr = synth.formula_clip(B, 1, H, W, seed=5)[:, 0]
+    hr = synth.formula_target(B, H * s, W * s, seed=7)
+    m = sr_oracle.OracleSR(3, s, Fc, N, win)
+    m.load_named(sd)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    m.train()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = F.mse_loss(m(lr.unsqueeze(1).expand(-1, 3, -1, -1, -1)), hr)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, g["losses"], rtol=2e-5)
+    m.eval()
+    with torch.no_grad():
+        out = m(lr.unsqueeze(1).expand(-1, 3, -1, -1, -1))
+    assert np.abs(out.numpy() - g["eval_output"]).max() < 2e-4
+    assert abs(sr_oracle.compute_psnr(out, hr) - float(g["psnr"])) < 1e-3
+
+
+def test_param_inventory_counts():
+    # 131 tensors / 1 987 283 params (cfg2), 83 / 820 339 (cfg1), 131 / 2 082 937 (cfg4)
+    for kw, n_t, n_p in (
+        (dict(num_features=64, num_residual_blocks=8), 131, 1987283),
+        (dict(num_features=32, num_residual_blocks=4), 83, 820339),
+        (dict(num_features=64, num_residual_blocks=8, temporal_window=2, scale_factor=4), 131, 2082937),
+    ):
+        shp = sr_oracle.param_shapes(**kw)
+        assert len(shp) == n_t
+        assert sum(int(np.prod(v)) for v in shp.values()) == n_p
+
+
+def test_bicubic_phase_weights():
+    # separable Keys cubic A=-0.75 phase weights for s=2
+    x = torch.zeros(1, 1, 1, 9)
+    x[0, 0, 0, 4] = 1.0
+    y = sr_oracle.bicubic_up(x, 2)[0, 0, 0]
+    # output 2*4+0 = 8 uses phase0 weights [-0.03515625, 0.26171875, 0.87890625, -0.10546875] on taps 2..5
+    assert abs(y[8].item() - 0.87890625) < 1e-7
+    assert abs(y[9].item() - 0.87890625) < 1e-7
+    assert abs(y[10].item() - 0.26171875) < 1e-7
+    assert abs(y[7].item() - 0.26171875) < 1e-7
