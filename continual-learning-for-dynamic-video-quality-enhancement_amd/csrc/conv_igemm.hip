@@ -1,0 +1,497 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, fp32 NHWC activations.
+//
+//   forward / input-gradient : D[cout][pixel] += W[cout][k] * X[k][pixel]      (M = cout, N = pixels)
+//   weight-gradient          : D[cin][cout]   += X[pixel][cin]^T * dY[pixel][cout]  (K = pixels)
+//
+// NVQ_MATH_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32, bit-equal to an fmaf chain).
+// One workgroup = 256 threads = 4 waves = an 8 x 32 pixel tile; the halo tile of the current
+// 16-channel K chunk and the matching weight slab are staged in LDS, every wave owns two tile
+// rows (4 pixel blocks of 16) and all NB*16 output channels of the workgroup.
+#include "common.h"
+
+namespace nvq {
+
+constexpr int TH = 8;      // tile rows
+constexpr int TW = 32;     // tile cols
+constexpr int KC = 16;     // input channels per K chunk
+constexpr int XS_LD = 20;  // floats per staged pixel (16 + 4 pad: the 16 pixels of one B-fragment hit 16 distinct 16-B slots)
+constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
+constexpr int WGRAD_MAX_WG = 512;
+
+static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
+
+// ---------------------------------------------------------------- weight packing
+// wpack[cz][kc][tap][g][n][j]  (g = 0..3 lane group, n = 0..NT-1, j = 0..3) holds
+// W[cout = cz*NT + n][channel = kc*16 + 4g + j][tap]; zero outside the real extents.
+__global__ void pack_kernel(const float* __restrict__ w, int cout_w, int cin_w, int taps,
+                            int transpose, int cout_keep, int NT, int ncz, int nkc,
+                            float* __restrict__ wp) {
+    const long total = (long)ncz * nkc * taps * 4 * NT * 4;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long t = idx;
+        const int j = t & 3; t >>= 2;
+        const int n = t % NT; t /= NT;
+        const int g = t & 3; t >>= 2;
+        const int tap = t % taps; t /= taps;
+        const int kc = t % nkc; t /= nkc;
+        const int cz = (int)t;
+        const int co = cz * NT + n;
+        const int ch = kc * KC + 4 * g + j;
+        float v = 0.f;
+        if (!transpose) {
+            if (co < cout_w && ch < cin_w) v = w[((long)co * cin_w + ch) * taps + tap];
+        } else {
+            if (co < cout_keep && ch < cout_w) v = w[((long)ch * cin_w + co) * taps + (taps - 1 - tap)];
+        }
+        wp[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------- forward / dgrad
+template <int NB, int KS>
+__global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d, int tilesX,
+                                                           int tilesY, int nkc, int vec_ok) {
+    constexpr int NT = NB * 16;
+    constexpr int HALO = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int HW_ = TW + 2 * HALO;
+    constexpr int HH_ = TH + 2 * HALO;
+    constexpr int NPIX = HW_ * HH_;
+    constexpr int WS_FLOATS = TAPS * 4 * NT * 4;
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * XS_LD + WS_FLOATS];
+    float* xs = lds;
+    float* ws = lds + NPIX * XS_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int cz = blockIdx.y;
+    const int H = d.h, W = d.w;
+
+    f32x4 acc[NB][4];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* wp_base = d.wpack + (size_t)cz * nkc * WS_FLOATS;
+    const float* in = d.in + d.in_coff;
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        for (int item = tid; item < NPIX * 4; item += 256) {
+            const int hp = item >> 2, q = item & 3;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
+            const int ch = kc * KC + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch < d.cin)
+                v = ld4(in + ((size_t)(n * H + gy) * W + gx) * d.in_ld + ch);
+            st4(xs + hp * XS_LD + 4 * q, v);
+        }
+        const float* wsrc = wp_base + (size_t)kc * WS_FLOATS;
+        for (int i = tid; i < WS_FLOATS / 4; i += 256) st4(ws + 4 * i, ld4(wsrc + 4 * i));
+        __syncthreads();
+
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+            float4 xb[4];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int row = 2 * wave + (pb >> 1);
+                const int x0 = (pb & 1) * 16;
+                const int hp = (row + dy) * HW_ + x0 + c + dx;
+                xb[pb] = ld4(xs + hp * XS_LD + 4 * g);
+            }
+            float4 wa[NB];
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+                wa[cb] = ld4(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    const float a = j == 0 ? wa[cb].x : j == 1 ? wa[cb].y : j == 2 ? wa[cb].z : wa[cb].w;
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        const float b = j == 0 ? xb[pb].x : j == 1 ? xb[pb].y : j == 2 ? xb[pb].z : xb[pb].w;
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb][pb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: lane holds channels co..co+3 (co = cz*NT + cb*16 + 4g) of pixel (row, x0 + c)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int row = 2 * wave + (pb >> 1);
+        const int gy = ty * TH + row;
+        const int gx = tx * TW + (pb & 1) * 16 + c;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (size_t)(n * H + gy) * W + gx;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int co = cz * NT + cb * 16 + 4 * g;
+            if (co >= d.cout_store) continue;
+            float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
+            if (vec_ok) {
+                if (d.bias && co < d.cout) {
+                    const float4 b = ld4(d.bias + co);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= d.alpha;
+                if (d.out2) st4(d.out2 + pix * d.out2_ld + d.out2_coff + co, make_float4(v[0], v[1], v[2], v[3]));
+                if (d.res && co < d.res_cmax) {
+                    const float4 r = ld4(d.res + pix * d.res_ld + d.res_coff + co);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                float* op = d.out + pix * d.out_ld + d.out_coff + co;
+                if (d.accumulate) {
+                    const float4 o = ld4(op);
+                    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                }
+                if (d.mask && co >= d.mask_c0 && co < d.mask_c1) {
+                    const float4 m = ld4(d.mask + pix * d.mask_ld + d.mask_coff + co);
+                    if (!(m.x > 0.f)) v[0] = 0.f;
+                    if (!(m.y > 0.f)) v[1] = 0.f;
+                    if (!(m.z > 0.f)) v[2] = 0.f;
+                    if (!(m.w > 0.f)) v[3] = 0.f;
+                }
+                st4(op, make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ce = co + e;
+                    if (ce >= d.cout_store) continue;
+                    float x = v[e];
+                    if (d.bias && ce < d.cout) x += d.bias[ce];
+                    if (d.relu) x = fmaxf(x, 0.f);
+                    x *= d.alpha;
+                    if (d.out2) d.out2[pix * d.out2_ld + d.out2_coff + ce] = x;
+                    if (d.res && ce < d.res_cmax) x += d.res[pix * d.res_ld + d.res_coff + ce];
+                    float* op = d.out + pix * d.out_ld + d.out_coff + ce;
+                    if (d.accumulate) x += *op;
+                    if (d.mask && ce >= d.mask_c0 && ce < d.mask_c1 &&
+                        !(d.mask[pix * d.mask_ld + d.mask_coff + ce] > 0.f))
+                        x = 0.f;
+                    *op = x;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// grid (split, ci chunk of 32, co chunk of 32). Wave (cib, cob) owns the 16x16 block of
+// (ci, co) for all taps; K = the 256 pixels of a tile, 4 per MFMA.  LDS images are
+// [pixel][32 ch] with channel ^= (pixel & 1) << 4 so the two pixels read by one 32-lane
+// half land on disjoint banks.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc d, int tilesX,
+                                                            int tilesY, int ntiles, int nci,
+                                                            int nco) {
+    constexpr int HALO = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int HW_ = TW + 2 * HALO;
+    constexpr int HH_ = TH + 2 * HALO;
+    constexpr int NPIX = HW_ * HH_;
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * WG_C + TH * TW * WG_C];
+    float* xs = lds;
+    float* dys = lds + NPIX * WG_C;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int cib = wave >> 1, cob = wave & 1;
+    const int cic = blockIdx.y, coc = blockIdx.z;
+    const int H = d.h, W = d.w;
+    const float* x = d.x + d.x_coff;
+    const float* dy = d.dy + d.dy_coff;
+
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bt = tile;
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
+        __syncthreads();
+        for (int item = tid; item < NPIX * 8; item += 256) {
+            const int hp = item >> 3, q = item & 7;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
+            const int ch = cic * WG_C + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch < d.cin)
+                v = ld4(x + ((size_t)(n * H + gy) * W + gx) * d.x_ld + ch);
+            st4(xs + hp * WG_C + ((4 * q) ^ ((hp & 1) << 4)), v);
+        }
+        for (int item = tid; item < TH * TW * 8; item += 256) {
+            const int p = item >> 3, q = item & 7;
+            const int py = p / TW, px = p - py * TW;
+            const int gy = ty * TH + py, gx = tx * TW + px;
+            const int ch = coc * WG_C + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W) {
+                const float* src = dy + ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ch;
+                if (ch + 3 < d.cout) {
+                    v = ld4(src);
+                } else {
+                    if (ch < d.cout) v.x = src[0];
+                    if (ch + 1 < d.cout) v.y = src[1];
+                    if (ch + 2 < d.cout) v.z = src[2];
+                }
+            }
+            st4(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4)), v);
+        }
+        __syncthreads();
+
+#pragma unroll 2
+        for (int ks = 0; ks < TH * TW / 4; ++ks) {
+            const int p = 4 * ks + g;
+            const int py = p / TW, px = p - py * TW;
+            const float b = dys[p * WG_C + ((cob * 16 + r) ^ ((p & 1) << 4))];
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ddy = tap / KS, ddx = tap - ddy * KS;
+                const int hp = (py + ddy) * HW_ + px + ddx;
+                const float a = xs[hp * WG_C + ((cib * 16 + r) ^ ((hp & 1) << 4))];
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+
+    float* part = d.workspace +
+                  ((size_t)(blockIdx.x * nci + cic) * nco + coc) * (TAPS * WG_C * WG_C);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
+                                    int taps, int cout, int cin_w, float alpha, int accumulate,
+                                    float* __restrict__ dw) {
+    const long total = (long)cout * cin_w * taps;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int tap = idx % taps;
+        const int ci = (idx / taps) % cin_w;
+        const int co = (int)(idx / ((long)taps * cin_w));
+        const int cic = ci / WG_C, cil = ci % WG_C, coc = co / WG_C, col = co % WG_C;
+        const size_t stride = (size_t)nci * nco * taps * WG_C * WG_C;
+        const float* p = part + ((size_t)cic * nco + coc) * (taps * WG_C * WG_C) +
+                         (tap * WG_C + cil) * WG_C + col;
+        double s = 0.0;
+        for (int k = 0; k < nsplit; ++k) s += (double)p[k * stride];
+        const float v = alpha * (float)s;
+        dw[idx] = accumulate ? dw[idx] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------- column sums (bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, int coff,
+                                                     int C, int CP, long npix,
+                                                     float* __restrict__ part) {
+    __shared__ float red[256];
+    const int c = threadIdx.x % CP;
+    const int pl = threadIdx.x / CP;
+    const int lanes = 256 / CP;
+    float s = 0.f;
+    if (c < C)
+        for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes)
+            s += x[p * ld + coff + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < lanes; ++k) t += red[k * CP + c];
+        part[(long)blockIdx.x * C + c] = t;
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nblk, int K,
+                                       float alpha, float* __restrict__ out, int accumulate) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * K + k];
+    const float v = alpha * (float)s;
+    out[k] = accumulate ? out[k] + v : v;
+}
+
+int launch_reduce_partials(const float* part, int nblk, int K, float alpha, float* out,
+                           int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(K, 128)), dim3(128), 0, s, part, nblk,
+                       K, alpha, out, accumulate);
+    return check_launch("reduce_partials");
+}
+
+static int colsum_impl(const float* x, int ld, int coff, int C, long npix, float alpha, float* out,
+                       float* ws, size_t ws_bytes, int accumulate, hipStream_t s) {
+    NVQ_REQUIRE(C >= 1 && C <= 256, "colsum: C=%d out of range", C);
+    int CP = 1;
+    while (CP < C) CP <<= 1;
+    const int lanes = 256 / CP;
+    int nblk = ceil_div(npix, (long)lanes * 8);
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    if ((size_t)nblk * C * sizeof(float) > ws_bytes) {
+        set_error("colsum: workspace too small");
+        return NVQ_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, s, x, ld, coff, C, CP, npix, ws);
+    int rc = check_launch("colsum");
+    if (rc) return rc;
+    return launch_reduce_partials(ws, nblk, C, alpha, out, accumulate, s);
+}
+
+}  // namespace nvq
+
+using namespace nvq;
+
+extern "C" {
+
+size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize) {
+    const int NT = choose_nt(cout);
+    const size_t ncz = (cout + NT - 1) / NT, nkc = (cin_store + KC - 1) / KC;
+    return ncz * nkc * (size_t)(ksize * ksize) * 4 * NT * 4;
+}
+
+int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store,
+                  int cout_keep, float* wpack, void* stream) {
+    NVQ_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
+    const int cout = transpose ? cout_keep : cout_w;
+    const int cin_real = transpose ? cout_w : cin_w;
+    NVQ_REQUIRE(cin_store >= cin_real && cin_store % 4 == 0, "conv_pack: cin_store %d < %d or not %%4",
+                cin_store, cin_real);
+    NVQ_REQUIRE(!transpose || cout_keep <= cin_w, "conv_pack: cout_keep %d > cin_w %d", cout_keep, cin_w);
+    const int NT = choose_nt(cout);
+    const int ncz = (cout + NT - 1) / NT, nkc = (cin_store + KC - 1) / KC;
+    const long total = (long)ncz * nkc * ksize * ksize * 4 * NT * 4;
+    int nblk = ceil_div(total, 256);
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(pack_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w,
+                       ksize * ksize, transpose, cout_keep, NT, ncz, nkc, wpack);
+    return check_launch("conv_pack");
+}
+
+size_t nvq_sizeof_conv_desc(void) { return sizeof(nvq_conv_desc); }
+size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }
+
+int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
+    const nvq_conv_desc d = *dp;
+    NVQ_REQUIRE(d.math == NVQ_MATH_F32, "conv_forward: math mode %d not built", d.math);
+    NVQ_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv_forward: ksize %d", d.ksize);
+    NVQ_REQUIRE(d.cin > 0 && d.cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_coff % 4 == 0 &&
+                    aligned16(d.in),
+                "conv_forward: input must be 16-byte addressable (cin %d ld %d coff %d)", d.cin,
+                d.in_ld, d.in_coff);
+    NVQ_REQUIRE(d.cout > 0 && d.cout_store >= d.cout, "conv_forward: cout %d store %d", d.cout,
+                d.cout_store);
+    NVQ_REQUIRE(d.out_coff + d.cout_store <= d.out_ld, "conv_forward: output slice exceeds ld");
+    NVQ_REQUIRE(aligned16(d.wpack), "conv_forward: wpack alignment");
+    NVQ_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0, "conv_forward: empty shape");
+    const int NT = choose_nt(d.cout);
+    const int ncz = (d.cout_store + NT - 1) / NT;
+    NVQ_REQUIRE(ncz == (d.cout + NT - 1) / NT, "conv_forward: cout_store %d crosses a pack chunk", d.cout_store);
+    const int nkc = (d.cin + KC - 1) / KC;
+    const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
+    int vec_ok = d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && d.cout_store % 4 == 0 && aligned16(d.out) &&
+                 (d.cout % 4 == 0 || !d.bias);
+    if (d.bias && !aligned16(d.bias)) vec_ok = 0;
+    if (d.out2 && !(d.out2_ld % 4 == 0 && d.out2_coff % 4 == 0 && aligned16(d.out2))) vec_ok = 0;
+    if (d.res && !(d.res_ld % 4 == 0 && d.res_coff % 4 == 0 && d.res_cmax % 4 == 0 && aligned16(d.res))) vec_ok = 0;
+    if (d.mask && !(d.mask_ld % 4 == 0 && d.mask_coff % 4 == 0 && d.mask_c0 % 4 == 0 &&
+                    d.mask_c1 % 4 == 0 && aligned16(d.mask)))
+        vec_ok = 0;
+    const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
+    hipStream_t s = (hipStream_t)stream;
+#define NVQ_LAUNCH_CONV(NB, KS) \
+    hipLaunchKernelGGL((conv_f32_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
+    if (d.ksize == 3) {
+        if (NT == 16) NVQ_LAUNCH_CONV(1, 3);
+        else if (NT == 32) NVQ_LAUNCH_CONV(2, 3);
+        else NVQ_LAUNCH_CONV(4, 3);
+    } else {
+        if (NT == 16) NVQ_LAUNCH_CONV(1, 1);
+        else if (NT == 32) NVQ_LAUNCH_CONV(2, 1);
+        else NVQ_LAUNCH_CONV(4, 1);
+    }
+#undef NVQ_LAUNCH_CONV
+    return check_launch("conv_forward");
+}
+
+size_t nvq_wgrad_workspace_bytes(void) {
+    return (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C * sizeof(float) + (size_t)512 * 256 * sizeof(float);
+}
+
+int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
+    const nvq_wgrad_desc d = *dp;
+    NVQ_REQUIRE(d.math == NVQ_MATH_F32, "conv_wgrad: math mode %d not built", d.math);
+    NVQ_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv_wgrad: ksize %d", d.ksize);
+    NVQ_REQUIRE(d.cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_coff % 4 == 0 && aligned16(d.x),
+                "conv_wgrad: x must be 16-byte addressable");
+    NVQ_REQUIRE(d.dy_ld % 4 == 0 && d.dy_coff % 4 == 0 && aligned16(d.dy),
+                "conv_wgrad: dy must be 16-byte addressable");
+    NVQ_REQUIRE(d.cin_w > 0 && d.cin_w <= d.cin && d.cout > 0, "conv_wgrad: channels");
+    NVQ_REQUIRE(d.workspace_bytes >= nvq_wgrad_workspace_bytes(), "conv_wgrad: workspace too small");
+    const int taps = d.ksize * d.ksize;
+    const int nci = (d.cin_w + WG_C - 1) / WG_C, nco = (d.cout + WG_C - 1) / WG_C;
+    const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
+    const int ntiles = tilesX * tilesY * d.n;
+    int nsplit = WGRAD_MAX_WG / (nci * nco);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    NVQ_REQUIRE((size_t)nsplit * nci * nco * taps * WG_C * WG_C * sizeof(float) <= d.workspace_bytes,
+                "conv_wgrad: %d x %d channel chunks exceed the workspace", nci, nco);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nsplit, nci, nco);
+    if (d.ksize == 3)
+        hipLaunchKernelGGL((wgrad_f32_kernel<3>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
+    else
+        hipLaunchKernelGGL((wgrad_f32_kernel<1>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
+    int rc = check_launch("conv_wgrad");
+    if (rc) return rc;
+    const long total = (long)d.cout * d.cin_w * taps;
+    int nblk = ceil_div(total, 256);
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, d.workspace, nsplit, nci, nco,
+                       taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw);
+    rc = check_launch("conv_wgrad_reduce");
+    if (rc) return rc;
+    if (d.dbias) {
+        float* ws2 = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+        rc = colsum_impl(d.dy, d.dy_ld, d.dy_coff, d.cout, (long)d.n * d.h * d.w, d.alpha, d.dbias, ws2,
+                         (size_t)512 * 256 * sizeof(float), d.accumulate, s);
+    }
+    return rc;
+}
+
+int nvq_colsum(const float* x, int x_ld, int x_coff, int C, long npix, float alpha, float* out,
+               float* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+    return colsum_impl(x, x_ld, x_coff, C, npix, alpha, out, workspace, workspace_bytes, accumulate,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

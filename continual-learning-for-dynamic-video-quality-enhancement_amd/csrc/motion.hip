@@ -1,0 +1,336 @@
+// Motion estimation stages: 9x9 local correlation (forward + both gradients) and the
+// bilinear flow warp (forward + scatter/flow gradients).  fp32 NHWC.
+#include "common.h"
+
+namespace nvq {
+
+constexpr int CT_H = 8, CT_W = 32;    // pixel tile, one thread per pixel
+constexpr int CD = 4;                 // max displacement
+constexpr int CN = 2 * CD + 1;        // 9
+constexpr int ND = CN * CN;           // 81
+constexpr int CHW = CT_W + 2 * CD;    // 40
+constexpr int CHH = CT_H + 2 * CD;    // 16
+constexpr int CCH = 16;               // channels per staged chunk
+constexpr int CLD = 20;               // floats per staged pixel (pad: 16 consecutive pixels -> 16 distinct 16-B slots)
+
+// Stage the (CHH x CHW) halo tile of `src` image `n` for channels [ch0, ch0+16) into LDS.
+__device__ __forceinline__ void stage_halo(const float* __restrict__ src, int ld, int C, int n, int H, int W,
+                                           int ty0, int tx0, int ch0, float* xs) {
+    for (int item = threadIdx.x; item < CHH * CHW * 4; item += 256) {
+        const int hp = item >> 2, q = item & 3;
+        const int hy = hp / CHW, hx = hp - hy * CHW;
+        const int gy = ty0 + hy - CD, gx = tx0 + hx - CD;
+        const int ch = ch0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch < C)
+            v = ld4(src + ((size_t)(n * H + gy) * W + gx) * ld + ch);
+        st4(xs + hp * CLD + 4 * q, v);
+    }
+}
+
+// out[n,p,d] = (1/C) sum_c x1[n,p,c] * x2[n % x2_images, p + off(d), c]
+__global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__ x1, int x1_ld,
+                                                       const float* __restrict__ x2, int x2_ld,
+                                                       int x2_images, int C, int H, int W, int tilesX,
+                                                       int tilesY, float* __restrict__ out, int out_ld) {
+    __shared__ __attribute__((aligned(16))) float xs[CHH * CHW * CLD];
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int py = threadIdx.x / CT_W, px = threadIdx.x % CT_W;
+    const int gy = ty * CT_H + py, gx = tx * CT_W + px;
+    const bool inside = gy < H && gx < W;
+    const size_t pix = (size_t)(n * H + (inside ? gy : 0)) * W + (inside ? gx : 0);
+    float acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = 0.f;
+    for (int ch0 = 0; ch0 < C; ch0 += CCH) {
+        __syncthreads();
+        stage_halo(x2, x2_ld, C, n % x2_images, H, W, ty * CT_H, tx * CT_W, ch0, xs);
+        __syncthreads();
+        float4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (inside && ch0 + 4 * q < C) a[q] = ld4(x1 + pix * x1_ld + ch0 + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) {
+                const float* p = xs + ((py + i) * CHW + px + j) * CLD;
+                float s = acc[i * CN + j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = ld4(p + 4 * q);
+                    s += a[q].x * b.x; s += a[q].y * b.y; s += a[q].z * b.z; s += a[q].w * b.w;
+                }
+                acc[i * CN + j] = s;
+            }
+    }
+    if (!inside) return;
+    const float inv = 1.f / (float)C;
+    float* op = out + pix * out_ld;
+#pragma unroll
+    for (int k = 0; k < ND / 4; ++k)
+        st4(op + 4 * k, make_float4(acc[4 * k] * inv, acc[4 * k + 1] * inv, acc[4 * k + 2] * inv, acc[4 * k + 3] * inv));
+    st4(op + 80, make_float4(acc[80] * inv, 0.f, 0.f, 0.f));
+    for (int k = 84; k < out_ld; k += 4) st4(op + k, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// WHICH == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d]        * other[n % oi, p + off(d), c]
+// WHICH == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n,      q - off(d), c]
+template <int WHICH>
+__global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__ dcorr, int dcorr_ld,
+                                                       const float* __restrict__ other, int other_ld,
+                                                       int other_images, int C, int H, int W, int tilesX,
+                                                       int tilesY, float* __restrict__ dx, int dx_ld,
+                                                       int dx_coff, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float xs[CHH * CHW * CLD];
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int py = threadIdx.x / CT_W, px = threadIdx.x % CT_W;
+    const int gy = ty * CT_H + py, gx = tx * CT_W + px;
+    const bool inside = gy < H && gx < W;
+    const size_t pix = (size_t)(n * H + (inside ? gy : 0)) * W + (inside ? gx : 0);
+    float wgt[ND];
+    if (WHICH == 1) {
+#pragma unroll
+        for (int k = 0; k < ND / 4; ++k) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (inside) v = ld4(dcorr + pix * dcorr_ld + 4 * k);
+            wgt[4 * k] = v.x; wgt[4 * k + 1] = v.y; wgt[4 * k + 2] = v.z; wgt[4 * k + 3] = v.w;
+        }
+        wgt[80] = inside ? dcorr[pix * dcorr_ld + 80] : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) {
+                const int qy = gy - (i - CD), qx = gx - (j - CD);
+                float v = 0.f;
+                if (inside && qy >= 0 && qy < H && qx >= 0 && qx < W)
+                    v = dcorr[((size_t)(n * H + qy) * W + qx) * dcorr_ld + i * CN + j];
+                wgt[i * CN + j] = v;
+            }
+    }
+    const float inv = 1.f / (float)C;
+    for (int ch0 = 0; ch0 < C; ch0 += CCH) {
+        __syncthreads();
+        stage_halo(other, other_ld, C, n % other_images, H, W, ty * CT_H, tx * CT_W, ch0, xs);
+        __syncthreads();
+        float4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) {
+                const int hy = WHICH == 1 ? py + i : py + 2 * CD - i;
+                const int hx = WHICH == 1 ? px + j : px + 2 * CD - j;
+                const float* p = xs + (hy * CHW + hx) * CLD;
+                const float w = wgt[i * CN + j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = ld4(p + 4 * q);
+                    acc[q].x += w * b.x; acc[q].y += w * b.y; acc[q].z += w * b.z; acc[q].w += w * b.w;
+                }
+            }
+        if (inside) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ch0 + 4 * q >= C) continue;
+                float* op = dx + pix * dx_ld + dx_coff + ch0 + 4 * q;
+                float4 v = make_float4(acc[q].x * inv, acc[q].y * inv, acc[q].z * inv, acc[q].w * inv);
+                if (accumulate) {
+                    const float4 o = ld4(op);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                st4(op, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bilinear warp
+struct WarpGeom {
+    float ix, iy;
+    int x0, y0;           // north-west corner
+    float wnw, wne, wsw, wse;
+    bool vnw, vne, vsw, vse;
+};
+
+// Mirrors the reference's arithmetic: grid = 2*(x+flow)/(W-1) - 1 (super_resolution.py:129-133),
+// then grid_sample's align_corners=True un-normalisation ((g+1)/2)*(W-1).
+__device__ __forceinline__ WarpGeom warp_geom(float fx, float fy, int x, int y, int H, int W) {
+    WarpGeom g;
+    const float gxn = 2.0f * ((float)x + fx) / (float)(W - 1) - 1.0f;
+    const float gyn = 2.0f * ((float)y + fy) / (float)(H - 1) - 1.0f;
+    g.ix = ((gxn + 1.f) / 2.f) * (float)(W - 1);
+    g.iy = ((gyn + 1.f) / 2.f) * (float)(H - 1);
+    const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
+    // guard the int conversion against wild flows
+    g.x0 = (int)fminf(fmaxf(fx0, -2.f), (float)W + 1.f);
+    g.y0 = (int)fminf(fmaxf(fy0, -2.f), (float)H + 1.f);
+    const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
+    g.wnw = (x_se - g.ix) * (y_se - g.iy);
+    g.wne = (g.ix - fx0) * (y_se - g.iy);
+    g.wsw = (x_se - g.ix) * (g.iy - fy0);
+    g.wse = (g.ix - fx0) * (g.iy - fy0);
+    const bool finite_ok = (fx0 > -2.f) && (fx0 < (float)W + 1.f) && (fy0 > -2.f) && (fy0 < (float)H + 1.f);
+    const bool xl = g.x0 >= 0 && g.x0 < W, xr = g.x0 + 1 >= 0 && g.x0 + 1 < W;
+    const bool yt = g.y0 >= 0 && g.y0 < H, yb = g.y0 + 1 >= 0 && g.y0 + 1 < H;
+    g.vnw = finite_ok && xl && yt;
+    g.vne = finite_ok && xr && yt;
+    g.vsw = finite_ok && xl && yb;
+    g.vse = finite_ok && xr && yb;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ feat, int feat_ld,
+                                                       const float* __restrict__ flow, int flow_ld, int C,
+                                                       int H, int W, float* __restrict__ out, int out_ld,
+                                                       int out_coff, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pix = gid / C4;
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const long img = pix - ((long)y * W + x);  // first pixel of this image
+    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* base = feat + 4 * c4;
+    if (g.vnw) { const float4 v = ld4(base + (img + (long)g.y0 * W + g.x0) * feat_ld);
+        acc.x += v.x * g.wnw; acc.y += v.y * g.wnw; acc.z += v.z * g.wnw; acc.w += v.w * g.wnw; }
+    if (g.vne) { const float4 v = ld4(base + (img + (long)g.y0 * W + g.x0 + 1) * feat_ld);
+        acc.x += v.x * g.wne; acc.y += v.y * g.wne; acc.z += v.z * g.wne; acc.w += v.w * g.wne; }
+    if (g.vsw) { const float4 v = ld4(base + (img + (long)(g.y0 + 1) * W + g.x0) * feat_ld);
+        acc.x += v.x * g.wsw; acc.y += v.y * g.wsw; acc.z += v.z * g.wsw; acc.w += v.w * g.wsw; }
+    if (g.vse) { const float4 v = ld4(base + (img + (long)(g.y0 + 1) * W + g.x0 + 1) * feat_ld);
+        acc.x += v.x * g.wse; acc.y += v.y * g.wse; acc.z += v.z * g.wse; acc.w += v.w * g.wse; }
+    st4(out + pix * out_ld + out_coff + 4 * c4, acc);
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v, float w) {
+    atomicAdd(p + 0, v.x * w);
+    atomicAdd(p + 1, v.y * w);
+    atomicAdd(p + 2, v.z * w);
+    atomicAdd(p + 3, v.w * w);
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// C/4 must be a power of two <= 64 so the lanes of one pixel sit in one wave.
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
+                                                       const float* __restrict__ feat, int feat_ld,
+                                                       const float* __restrict__ flow, int flow_ld, int C,
+                                                       int H, int W, float* __restrict__ dfeat, int dfeat_ld,
+                                                       float* __restrict__ dflow, int dflow_ld, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pix = gid / C4;
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const long img = pix - ((long)y * W + x);
+    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+    const float4 go = ld4(dout + pix * dout_ld + dout_coff + 4 * c4);
+    const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
+    const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
+    float gix = 0.f, giy = 0.f;
+    const float* fb = feat + 4 * c4;
+    float* db = dfeat + 4 * c4;
+    if (g.vnw) { const long o = (img + (long)g.y0 * W + g.x0);
+        atomic_add4(db + o * dfeat_ld, go, g.wnw);
+        const float d = dot4(ld4(fb + o * feat_ld), go); gix -= d * (y_se - g.iy); giy -= d * (x_se - g.ix); }
+    if (g.vne) { const long o = (img + (long)g.y0 * W + g.x0 + 1);
+        atomic_add4(db + o * dfeat_ld, go, g.wne);
+        const float d = dot4(ld4(fb + o * feat_ld), go); gix += d * (y_se - g.iy); giy -= d * (g.ix - fx0); }
+    if (g.vsw) { const long o = (img + (long)(g.y0 + 1) * W + g.x0);
+        atomic_add4(db + o * dfeat_ld, go, g.wsw);
+        const float d = dot4(ld4(fb + o * feat_ld), go); gix -= d * (g.iy - fy0); giy += d * (x_se - g.ix); }
+    if (g.vse) { const long o = (img + (long)(g.y0 + 1) * W + g.x0 + 1);
+        atomic_add4(db + o * dfeat_ld, go, g.wse);
+        const float d = dot4(ld4(fb + o * feat_ld), go); gix += d * (g.iy - fy0); giy += d * (g.ix - fx0); }
+    gix = group_sum(gix, C4);
+    giy = group_sum(giy, C4);
+    if (c4 == 0) {
+        // grid_sample multiplies by (size-1)/2; the normalisation's autograd divides by (size-1) and doubles
+        const float gx = 2.0f * ((gix * ((float)(W - 1) / 2.f)) / (float)(W - 1));
+        const float gyv = 2.0f * ((giy * ((float)(H - 1) / 2.f)) / (float)(H - 1));
+        float* dp = dflow + pix * dflow_ld;
+        dp[0] = gx;
+        dp[1] = gyv;
+        for (int k = 2; k < dflow_ld; ++k) dp[k] = 0.f;
+    }
+}
+
+}  // namespace nvq
+
+using namespace nvq;
+
+extern "C" {
+
+int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C,
+                            int N, int H, int W, float* out, int out_ld, void* stream) {
+    NVQ_REQUIRE(C % 4 == 0 && x1_ld % 4 == 0 && x2_ld % 4 == 0 && out_ld % 4 == 0 && out_ld >= 84 &&
+                    aligned16(x1) && aligned16(x2) && aligned16(out),
+                "correlation_forward: alignment (C %d out_ld %d)", C, out_ld);
+    NVQ_REQUIRE(x2_images > 0, "correlation_forward: x2_images");
+    const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
+    hipLaunchKernelGGL(corr_fwd_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, (hipStream_t)stream,
+                       x1, x1_ld, x2, x2_ld, x2_images, C, H, W, tilesX, tilesY, out, out_ld);
+    return check_launch("correlation_forward");
+}
+
+int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const float* other, int other_ld,
+                             int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff,
+                             int accumulate, void* stream) {
+    NVQ_REQUIRE(which == 1 || which == 2, "correlation_backward: which %d", which);
+    NVQ_REQUIRE(C % 4 == 0 && dcorr_ld % 4 == 0 && dcorr_ld >= 84 && other_ld % 4 == 0 && dx_ld % 4 == 0 &&
+                    dx_coff % 4 == 0 && aligned16(dcorr) && aligned16(other) && aligned16(dx),
+                "correlation_backward: alignment");
+    NVQ_REQUIRE(other_images > 0, "correlation_backward: other_images");
+    const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
+    const dim3 grid((unsigned)((long)tilesX * tilesY * N));
+    if (which == 1)
+        hipLaunchKernelGGL((corr_bwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, dcorr, dcorr_ld, other, other_ld,
+                           other_images, C, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate);
+    else
+        hipLaunchKernelGGL((corr_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, dcorr, dcorr_ld, other, other_ld,
+                           other_images, C, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate);
+    return check_launch("correlation_backward");
+}
+
+int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
+                     float* out, int out_ld, int out_coff, void* stream) {
+    NVQ_REQUIRE(C % 4 == 0 && feat_ld % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0 && flow_ld >= 2 &&
+                    aligned16(feat) && aligned16(out),
+                "warp_forward: alignment");
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, feat_ld,
+                       flow, flow_ld, C, H, W, out, out_ld, out_coff, total);
+    return check_launch("warp_forward");
+}
+
+int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
+                      const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
+                      float* dflow, int dflow_ld, void* stream) {
+    const int c4 = C >> 2;
+    NVQ_REQUIRE(C % 4 == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0,
+                "warp_backward: C %d must be a power of two in [4,256]", C);
+    NVQ_REQUIRE(dout_ld % 4 == 0 && dout_coff % 4 == 0 && feat_ld % 4 == 0 && dfeat_ld % 4 == 0 && flow_ld >= 2 &&
+                    dflow_ld >= 2,
+                "warp_backward: alignment");
+    const long total = (long)N * H * W * c4;
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
+                       dout_coff, feat, feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, total);
+    return check_launch("warp_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,604 @@
+// Memory-bound stages of the feature extractor (head conv, depthwise conv, BatchNorm) and
+// slice helpers.  fp32 NHWC; one thread = 4 consecutive channels of one pixel, so a pixel's
+// C floats are read/written by C/4 adjacent lanes as contiguous 16-byte pieces.
+#include "common.h"
+
+namespace nvq {
+
+struct SlotMap { int t[NVQ_MAX_T]; };
+
+// ---------------------------------------------------------------- head conv (NCHW image -> NHWC features)
+template <int CIN>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ frames, int B, int T,
+                                                       int H, int W, SlotMap sm,
+                                                       const float* __restrict__ weight,
+                                                       const float* __restrict__ bias, int F,
+                                                       float* __restrict__ out, int out_ld,
+                                                       long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [CIN*9][F] then bias[F]
+    const int K = CIN * 9;
+    for (int i = threadIdx.x; i < K * F; i += 256) {
+        const int co = i % F, k = i / F;
+        wl[i] = weight[co * K + k];
+    }
+    for (int i = threadIdx.x; i < F; i += 256) wl[K * F + i] = bias[i];
+    __syncthreads();
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int F4 = F >> 2;
+    const int c4 = gid % F4;
+    const long pixlin = gid / F4;
+    const int x = pixlin % W;
+    const int y = (pixlin / W) % H;
+    const int n = pixlin / ((long)W * H);
+    const int slot = n / B, b = n - slot * B;
+    const float* img = frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W;
+    float4 acc = ld4(wl + K * F + 4 * c4);
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x + dx - 1;
+                float v = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((size_t)ci * H + yy) * W + xx];
+                const float4 w = ld4(wl + (ci * 9 + dy * 3 + dx) * F + 4 * c4);
+                acc.x += v * w.x; acc.y += v * w.y; acc.z += v * w.z; acc.w += v * w.w;
+            }
+        }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    st4(out + pixlin * out_ld + 4 * c4, acc);
+}
+
+// Cross pixel-lane reduction of a float4 inside a 256-thread block whose threads are laid out
+// as (pixel lane, c4) with C4 lanes per pixel.  Threads with pixel lane 0 get the sum.
+__device__ __forceinline__ float4 plane_reduce4(float4 v, float4* buf, int C4, int npl) {
+    __syncthreads();
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((int)threadIdx.x < C4) {
+        for (int k = 0; k < npl; ++k) {
+            const float4 t = buf[k * C4 + threadIdx.x];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    return s;
+}
+
+// dW[co][ci][tap], db[co] partials: part[blk][F*CIN*9 + F]
+template <int CIN>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ frames, int B, int T,
+                                                         int H, int W, SlotMap sm,
+                                                         const float* __restrict__ dout, int dout_ld,
+                                                         const float* __restrict__ act, int act_ld,
+                                                         int F, long npix, float* __restrict__ part) {
+    __shared__ float4 buf[256];
+    constexpr int K = CIN * 9;
+    const int F4 = F >> 2;
+    const int npl = 256 / F4;  // F4 is a power of two <= 64
+    const int c4 = threadIdx.x % F4;
+    const int pl = threadIdx.x / F4;
+    float4 acc[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
+        const int x = p % W;
+        const int y = (p / W) % H;
+        const int n = p / ((long)W * H);
+        const int slot = n / B, b = n - slot * B;
+        const float* img = frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W;
+        float4 g = ld4(dout + p * dout_ld + 4 * c4);
+        const float4 a = ld4(act + p * act_ld + 4 * c4);
+        if (!(a.x > 0.f)) g.x = 0.f;
+        if (!(a.y > 0.f)) g.y = 0.f;
+        if (!(a.z > 0.f)) g.z = 0.f;
+        if (!(a.w > 0.f)) g.w = 0.f;
+        acc[K].x += g.x; acc[K].y += g.y; acc[K].z += g.z; acc[K].w += g.w;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = x + dx - 1;
+                    float v = 0.f;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((size_t)ci * H + yy) * W + xx];
+                    float4& s = acc[ci * 9 + dy * 3 + dx];
+                    s.x += v * g.x; s.y += v * g.y; s.z += v * g.z; s.w += v * g.w;
+                }
+            }
+    }
+    float* prow = part + (size_t)blockIdx.x * (F * K + F);
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        const float4 s = plane_reduce4(acc[k], buf, F4, npl);
+        if ((int)threadIdx.x < F4) {
+            const int co = 4 * c4;
+            if (k < K) {
+                prow[(co + 0) * K + k] = s.x; prow[(co + 1) * K + k] = s.y;
+                prow[(co + 2) * K + k] = s.z; prow[(co + 3) * K + k] = s.w;
+            } else {
+                st4(prow + F * K + co, s);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- depthwise 3x3
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in, int in_ld,
+                                                     const float* __restrict__ weight, int C,
+                                                     float* __restrict__ out, int out_ld, int H, int W,
+                                                     int flip, long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
+    for (int i = threadIdx.x; i < 9 * C; i += 256) {
+        const int c = i % C, tap = i / C;
+        wl[i] = weight[c * 9 + (flip ? 8 - tap : tap)];
+    }
+    __syncthreads();
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pixlin = gid / C4;
+    const int x = pixlin % W;
+    const int y = (pixlin / W) % H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = x + dx - 1;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v = ld4(in + (pixlin + (long)(dy - 1) * W + (dx - 1)) * in_ld + 4 * c4);
+            const float4 w = ld4(wl + (dy * 3 + dx) * C + 4 * c4);
+            acc.x += v.x * w.x; acc.y += v.y * w.y; acc.z += v.z * w.z; acc.w += v.w * w.w;
+        }
+    }
+    st4(out + pixlin * out_ld + 4 * c4, acc);
+}
+
+// part[blk][C*9]
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, int x_ld,
+                                                           const float* __restrict__ dy, int dy_ld, int C,
+                                                           int H, int W, long npix,
+                                                           float* __restrict__ part) {
+    __shared__ float4 buf[256];
+    const int C4 = C >> 2;
+    const int npl = 256 / C4;
+    const int c4 = threadIdx.x % C4;
+    const int pl = threadIdx.x / C4;
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
+        const int xx0 = p % W;
+        const int yy0 = (p / W) % H;
+        const float4 g = ld4(dy + p * dy_ld + 4 * c4);
+#pragma unroll
+        for (int ddy = 0; ddy < 3; ++ddy) {
+            const int yy = yy0 + ddy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int ddx = 0; ddx < 3; ++ddx) {
+                const int xx = xx0 + ddx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const float4 v = ld4(x + (p + (long)(ddy - 1) * W + (ddx - 1)) * x_ld + 4 * c4);
+                float4& s = acc[ddy * 3 + ddx];
+                s.x += v.x * g.x; s.y += v.y * g.y; s.z += v.z * g.z; s.w += v.w * g.w;
+            }
+        }
+    }
+    float* prow = part + (size_t)blockIdx.x * C * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float4 s = plane_reduce4(acc[k], buf, C4, npl);
+        if ((int)threadIdx.x < C4) {
+            const int c = 4 * c4;
+            prow[(c + 0) * 9 + k] = s.x; prow[(c + 1) * 9 + k] = s.y;
+            prow[(c + 2) * 9 + k] = s.z; prow[(c + 3) * 9 + k] = s.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- BatchNorm
+// grid (blocks per group, G): part[g][blk][2C] = {sum, sum of squares}
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int x_ld, int C,
+                                                       long group_pix, float* __restrict__ part) {
+    __shared__ float4 buf[256];
+    const int C4 = C >> 2;
+    const int npl = 256 / C4;
+    const int c4 = threadIdx.x % C4;
+    const int pl = threadIdx.x / C4;
+    const long base = (long)blockIdx.y * group_pix;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    for (long p = (long)blockIdx.x * npl + pl; p < group_pix; p += (long)gridDim.x * npl) {
+        const float4 v = ld4(x + (base + p) * x_ld + 4 * c4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+    float* prow = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+    const float4 rs = plane_reduce4(s, buf, C4, npl);
+    if ((int)threadIdx.x < C4) st4(prow + 4 * c4, rs);
+    const float4 rq = plane_reduce4(q, buf, C4, npl);
+    if ((int)threadIdx.x < C4) st4(prow + C + 4 * c4, rq);
+}
+
+struct GroupOrder { int g[NVQ_MAX_T]; };
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
+                                   long group_pix, float eps, float momentum, GroupOrder order,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+    for (int gi = 0; gi < G; ++gi) {
+        const int g = order.g[gi];
+        double s = 0.0, q = 0.0;
+        const float* p = part + (size_t)g * nblk * 2 * C;
+        for (int b = 0; b < nblk; ++b) {
+            s += (double)p[(size_t)b * 2 * C + c];
+            q += (double)p[(size_t)b * 2 * C + C + c];
+        }
+        const double m = s / (double)group_pix;
+        double var = q / (double)group_pix - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[g * C + c] = (float)m;
+        invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unb = group_pix > 1 ? var * (double)group_pix / (double)(group_pix - 1) : var;
+        rm = (1.f - momentum) * rm + momentum * (float)m;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+    }
+    if (rmean) rmean[c] = rm;
+    if (rvar) rvar[c] = rv;
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                     int C, int G, float eps, float* __restrict__ mean,
+                                     float* __restrict__ invstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * G) return;
+    const int c = i % C;
+    mean[i] = rmean[c];
+    invstd[i] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(
+    const float* __restrict__ x, int x_ld, int C, long img_pix, int group_images,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res, int res_ld, float* __restrict__ outA,
+    int outA_ld, int outA_coff, int split_images, float* __restrict__ outB, int outB_ld, int outB_coff,
+    long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pix = gid / C4;
+    const int n = pix / img_pix;
+    const int g = n / group_images;
+    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
+    const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
+    float4 y;
+    y.x = fmaxf((v.x - m.x) * is.x * ga.x + be.x, 0.f);
+    y.y = fmaxf((v.y - m.y) * is.y * ga.y + be.y, 0.f);
+    y.z = fmaxf((v.z - m.z) * is.z * ga.z + be.z, 0.f);
+    y.w = fmaxf((v.w - m.w) * is.w * ga.w + be.w, 0.f);
+    if (res) {
+        const float4 r = ld4(res + pix * res_ld + 4 * c4);
+        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    }
+    if (n < split_images)
+        st4(outA + pix * outA_ld + outA_coff + 4 * c4, y);
+    else
+        st4(outB + (pix - (long)split_images * img_pix) * outB_ld + outB_coff + 4 * c4, y);
+}
+
+// backward pass 1: part[g][blk][2C] = {sum dyr, sum dyr*xhat}, dyr = dy * [bn(x) > 0]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C,
+    long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part) {
+    __shared__ float4 buf[256];
+    const int C4 = C >> 2;
+    const int npl = 256 / C4;
+    const int c4 = threadIdx.x % C4;
+    const int pl = threadIdx.x / C4;
+    const int g = blockIdx.y;
+    const long base = (long)g * group_pix;
+    const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
+    const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (long p = (long)blockIdx.x * npl + pl; p < group_pix; p += (long)gridDim.x * npl) {
+        const float4 v = ld4(x + (base + p) * x_ld + 4 * c4);
+        float4 d = ld4(dy + (base + p) * dy_ld + 4 * c4);
+        const float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z,
+                    hw = (v.w - m.w) * is.w;
+        if (!(hx * ga.x + be.x > 0.f)) d.x = 0.f;
+        if (!(hy * ga.y + be.y > 0.f)) d.y = 0.f;
+        if (!(hz * ga.z + be.z > 0.f)) d.z = 0.f;
+        if (!(hw * ga.w + be.w > 0.f)) d.w = 0.f;
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * hx; s2.y += d.y * hy; s2.z += d.z * hz; s2.w += d.w * hw;
+    }
+    float* prow = part + ((size_t)g * gridDim.x + blockIdx.x) * 2 * C;
+    const float4 r1 = plane_reduce4(s1, buf, C4, npl);
+    if ((int)threadIdx.x < C4) st4(prow + 4 * c4, r1);
+    const float4 r2 = plane_reduce4(s2, buf, C4, npl);
+    if ((int)threadIdx.x < C4) st4(prow + C + 4 * c4, r2);
+}
+
+// sums[g][2C] (device), dgamma/dbeta
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
+                                       float* __restrict__ sums, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        const float* p = part + (size_t)g * nblk * 2 * C;
+        for (int b = 0; b < nblk; ++b) {
+            s1 += (double)p[(size_t)b * 2 * C + c];
+            s2 += (double)p[(size_t)b * 2 * C + C + c];
+        }
+        sums[(size_t)g * 2 * C + c] = (float)s1;
+        sums[(size_t)g * 2 * C + C + c] = (float)s2;
+        tb += s1;
+        tg += s2;
+    }
+    dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
+    dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C, long img_pix,
+    int group_images, long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
+    int training, float* __restrict__ dx, int dx_ld, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pix = gid / C4;
+    const int g = (pix / img_pix) / group_images;
+    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 d0 = ld4(dy + pix * dy_ld + 4 * c4);
+    const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
+    const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (training) {
+        s1 = ld4(sums + (size_t)g * 2 * C + 4 * c4);
+        s2 = ld4(sums + (size_t)g * 2 * C + C + 4 * c4);
+    }
+    const float inv_n = 1.f / (float)group_pix;
+    float dv[4] = {d0.x, d0.y, d0.z, d0.w};
+    const float xv[4] = {v.x, v.y, v.z, v.w}, mv[4] = {m.x, m.y, m.z, m.w}, iv[4] = {is.x, is.y, is.z, is.w};
+    const float gv[4] = {ga.x, ga.y, ga.z, ga.w}, bv[4] = {be.x, be.y, be.z, be.w};
+    const float a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float h = (xv[e] - mv[e]) * iv[e];
+        const float d = (h * gv[e] + bv[e] > 0.f) ? dv[e] : 0.f;
+        o[e] = training ? gv[e] * iv[e] * (d - a1[e] * inv_n - h * a2[e] * inv_n) : gv[e] * iv[e] * d;
+    }
+    st4(dx + pix * dx_ld + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+}
+
+// ---------------------------------------------------------------- slice axpy
+__global__ __launch_bounds__(256) void axpy_slice_kernel(float* __restrict__ dst, int dst_ld, int dst_coff,
+                                                         const float* __restrict__ src, int src_ld,
+                                                         int src_coff, const float* __restrict__ mask,
+                                                         int mask_ld, int mask_coff, int C, float alpha,
+                                                         int accumulate, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = gid % C4;
+    const long pix = gid / C4;
+    float4 v = ld4(src + pix * src_ld + src_coff + 4 * c4);
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    if (mask) {
+        const float4 m = ld4(mask + pix * mask_ld + mask_coff + 4 * c4);
+        if (!(m.x > 0.f)) v.x = 0.f;
+        if (!(m.y > 0.f)) v.y = 0.f;
+        if (!(m.z > 0.f)) v.z = 0.f;
+        if (!(m.w > 0.f)) v.w = 0.f;
+    }
+    float* dp = dst + pix * dst_ld + dst_coff + 4 * c4;
+    if (accumulate) {
+        const float4 o = ld4(dp);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    st4(dp, v);
+}
+
+static bool pow2_c4(int C) {
+    const int c4 = C >> 2;
+    return C % 4 == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0;
+}
+static int blocks_for(long npix, int C) {
+    const int npl = 256 / (C >> 2);
+    int nb = ceil_div(npix, (long)npl * 16);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+}  // namespace nvq
+
+using namespace nvq;
+
+extern "C" {
+
+int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
+                     const int* t_of_slot_host, int nslots, const float* weight, const float* bias,
+                     int F, float* out, int out_ld, void* stream) {
+    NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_forward: in_channels %d not supported (1 or 3)", Cin);
+    NVQ_REQUIRE(F % 4 == 0 && F <= 256 && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d / ld %d", F, out_ld);
+    NVQ_REQUIRE(nslots >= 1 && nslots <= NVQ_MAX_T && T <= NVQ_MAX_T, "head_forward: T %d slots %d", T, nslots);
+    SlotMap sm;
+    for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
+    const long total = (long)nslots * B * H * W * (F / 4);
+    const size_t shm = (size_t)(Cin * 9 * F + F) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 3)
+        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(ceil_div(total, 256)), dim3(256), shm, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, total);
+    else
+        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(ceil_div(total, 256)), dim3(256), shm, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, total);
+    return check_launch("head_forward");
+}
+
+int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, const int* t_of_slot_host,
+                   int nslots, const float* dout, int dout_ld, const float* act, int act_ld, int F,
+                   float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
+                   int accumulate, void* stream) {
+    NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_wgrad: in_channels %d not supported (1 or 3)", Cin);
+    NVQ_REQUIRE(pow2_c4(F), "head_wgrad: F %d must be a power of two in [4,256]", F);
+    NVQ_REQUIRE(dout_ld % 4 == 0 && act_ld % 4 == 0, "head_wgrad: ld");
+    SlotMap sm;
+    for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
+    const long npix = (long)nslots * B * H * W;
+    const int K = Cin * 9;
+    int nblk = blocks_for(npix, F);
+    if (nblk > 256) nblk = 256;
+    const size_t row = (size_t)F * K + F;
+    if (row * nblk * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 3)
+        hipLaunchKernelGGL((head_wgrad_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, npix, workspace);
+    else
+        hipLaunchKernelGGL((head_wgrad_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, npix, workspace);
+    int rc = check_launch("head_wgrad");
+    if (rc) return rc;
+    // rows are [F*K weights | F biases]; reduce the two pieces separately (row stride = row)
+    // by viewing the partials as nblk rows of `row` floats.
+    // launch_reduce_partials expects dense rows, so reduce the whole row into a scratch tail.
+    float* scratch = workspace + row * nblk;
+    if ((row * (nblk + 1)) * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
+    rc = launch_reduce_partials(workspace, nblk, (int)row, 1.f, scratch, 0, s);
+    if (rc) return rc;
+    rc = nvq_axpy_slice(dweight, F * K, 0, scratch, F * K, 0, nullptr, 0, 0, F * K, 1, 1.f, accumulate, stream);
+    if (rc) return rc;
+    return nvq_axpy_slice(dbias, F, 0, scratch + F * K, F, 0, nullptr, 0, 0, F, 1, 1.f, accumulate, stream);
+}
+
+int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, float* out, int out_ld,
+                       int N, int H, int W, int flip, void* stream) {
+    NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
+                "dwconv_forward: C %d ld %d/%d", C, in_ld, out_ld);
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(ceil_div(total, 256)), dim3(256), (size_t)9 * C * sizeof(float),
+                       (hipStream_t)stream, in, in_ld, weight, C, out, out_ld, H, W, flip, total);
+    return check_launch("dwconv_forward");
+}
+
+int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C, int N, int H, int W,
+                     float* dweight, float* workspace, size_t workspace_bytes, int accumulate,
+                     void* stream) {
+    NVQ_REQUIRE(pow2_c4(C), "dwconv_wgrad: C %d must be a power of two in [4,256]", C);
+    NVQ_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0, "dwconv_wgrad: ld");
+    const long npix = (long)N * H * W;
+    const int nblk = blocks_for(npix, C);
+    if ((size_t)nblk * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy, dy_ld, C, H, W, npix, workspace);
+    int rc = check_launch("dwconv_wgrad");
+    if (rc) return rc;
+    return launch_reduce_partials(workspace, nblk, C * 9, 1.f, dweight, accumulate, (hipStream_t)stream);
+}
+
+int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H, int W, float eps,
+                 float momentum, const int* order_host, float* mean, float* invstd, float* running_mean,
+                 float* running_var, float* workspace, size_t workspace_bytes, void* stream) {
+    NVQ_REQUIRE(pow2_c4(C), "bn_stats: C %d must be a power of two in [4,256]", C);
+    NVQ_REQUIRE(group_images > 0 && N % group_images == 0 && N / group_images <= NVQ_MAX_T, "bn_stats: groups");
+    NVQ_REQUIRE(x_ld % 4 == 0 && aligned16(x), "bn_stats: ld");
+    const int G = N / group_images;
+    const long group_pix = (long)group_images * H * W;
+    const int nblk = blocks_for(group_pix, C);
+    if ((size_t)G * nblk * 2 * C * sizeof(float) > workspace_bytes) { set_error("bn_stats: workspace"); return NVQ_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, G), dim3(256), 0, s, x, x_ld, C, group_pix, workspace);
+    int rc = check_launch("bn_stats");
+    if (rc) return rc;
+    GroupOrder order;
+    for (int i = 0; i < NVQ_MAX_T; ++i) order.g[i] = i < G ? (order_host ? order_host[i] : i) : 0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, workspace, nblk, C, G, group_pix,
+                       eps, momentum, order, mean, invstd, running_mean, running_var);
+    return check_launch("bn_finalize");
+}
+
+int nvq_bn_eval_stats(const float* running_mean, const float* running_var, int C, int G, float eps,
+                      float* mean, float* invstd, void* stream) {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div((long)C * G, 256)), dim3(256), 0, (hipStream_t)stream,
+                       running_mean, running_var, C, G, eps, mean, invstd);
+    return check_launch("bn_eval_stats");
+}
+
+int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, int H, int W,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* res, int res_ld, float* outA, int outA_ld, int outA_coff,
+                      int split_images, float* outB, int outB_ld, int outB_coff, void* stream) {
+    NVQ_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && outA_ld % 4 == 0 && outA_coff % 4 == 0 && outB_ld % 4 == 0 &&
+                    outB_coff % 4 == 0 && (!res || res_ld % 4 == 0),
+                "bn_apply_relu: alignment");
+    NVQ_REQUIRE(split_images >= N || outB, "bn_apply_relu: outB missing");
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                       C, (long)H * W, group_images, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld,
+                       outA_coff, split_images, outB, outB_ld, outB_coff, total);
+    return check_launch("bn_apply_relu");
+}
+
+int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C, int N,
+                         int group_images, int H, int W, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, int training, float* dx, int dx_ld,
+                         float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                         int accumulate, void* stream) {
+    NVQ_REQUIRE(pow2_c4(C), "bn_relu_backward: C %d must be a power of two in [4,256]", C);
+    NVQ_REQUIRE(dy_ld % 4 == 0 && x_ld % 4 == 0 && dx_ld % 4 == 0, "bn_relu_backward: ld");
+    NVQ_REQUIRE(group_images > 0 && N % group_images == 0 && N / group_images <= NVQ_MAX_T, "bn_relu_backward: groups");
+    const int G = N / group_images;
+    const long group_pix = (long)group_images * H * W;
+    const int nblk = blocks_for(group_pix, C);
+    const size_t part_floats = (size_t)G * nblk * 2 * C;
+    if ((part_floats + (size_t)G * 2 * C) * sizeof(float) > workspace_bytes) { set_error("bn_relu_backward: workspace"); return NVQ_EWORKSPACE; }
+    float* sums = workspace + part_floats;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, G), dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, mean,
+                       invstd, gamma, beta, workspace);
+    int rc = check_launch("bn_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, workspace, nblk, C, G, sums,
+                       dgamma, dbeta, accumulate);
+    rc = check_launch("bn_bwd_finalize");
+    if (rc) return rc;
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dy, dy_ld, x, x_ld, C,
+                       (long)H * W, group_images, group_pix, mean, invstd, gamma, beta, sums, training, dx, dx_ld,
+                       total);
+    return check_launch("bn_bwd_apply");
+}
+
+int nvq_axpy_slice(float* dst, int dst_ld, int dst_coff, const float* src, int src_ld, int src_coff,
+                   const float* mask, int mask_ld, int mask_coff, int C, long npix, float alpha,
+                   int accumulate, void* stream) {
+    NVQ_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && src_ld % 4 == 0 && src_coff % 4 == 0 &&
+                    (!mask || (mask_ld % 4 == 0 && mask_coff % 4 == 0)) && aligned16(dst) && aligned16(src),
+                "axpy_slice: alignment (C %d ld %d/%d)", C, dst_ld, src_ld);
+    const long total = npix * (C / 4);
+    if (total == 0) return NVQ_OK;
+    hipLaunchKernelGGL(axpy_slice_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld,
+                       dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total);
+    return check_launch("axpy_slice");
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Upsampler tail: PixelShuffle + bicubic skip + clamp (forward), clamp mask + un-shuffle (backward).
+#include "common.h"
+
+namespace nvq {
+
+// Keys cubic convolution, A = -0.75 (PyTorch upsample_bicubic2d, align_corners=False)
+__device__ __forceinline__ float cc1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__device__ __forceinline__ void cubic_taps(int dst, float scale, int size, int idx[4], float w[4]) {
+    const float real = scale * ((float)dst + 0.5f) - 0.5f;
+    const float fl = floorf(real);
+    const float t = real - fl;
+    const int i0 = (int)fl;
+    w[0] = cc2(t + 1.f);
+    w[1] = cc1(t);
+    w[2] = cc1(1.f - t);
+    w[3] = cc2((1.f - t) + 1.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(i0 - 1 + k, 0), size - 1);
+}
+
+// one thread per HR pixel (b, oy, ox); loops over image channels
+__global__ __launch_bounds__(256) void shuffle_bicubic_clamp_kernel(const float* __restrict__ u, int u_ld,
+                                                                     const float* __restrict__ frames, int T,
+                                                                     int t_center, int Cimg, int H, int W, int s,
+                                                                     float scale, float* __restrict__ out,
+                                                                     uint8_t* __restrict__ pass, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int OW = W * s, OH = H * s;
+    const int ox = gid % OW;
+    const int oy = (gid / OW) % OH;
+    const int b = gid / ((long)OW * OH);
+    const int h = oy / s, i = oy - h * s, w = ox / s, j = ox - w * s;
+    int xi[4], yi[4];
+    float wx[4], wy[4];
+    cubic_taps(ox, scale, W, xi, wx);
+    cubic_taps(oy, scale, H, yi, wy);
+    const float* up = u + ((size_t)(b * H + h) * W + w) * u_ld + i * s + j;
+    for (int c = 0; c < Cimg; ++c) {
+        const float* img = frames + ((size_t)(b * T + t_center) * Cimg + c) * H * W;
+        float bic = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float* row = img + (size_t)yi[a] * W;
+            const float r = wx[0] * row[xi[0]] + wx[1] * row[xi[1]] + wx[2] * row[xi[2]] + wx[3] * row[xi[3]];
+            bic += wy[a] * r;
+        }
+        const float pre = bic + up[c * s * s];
+        const size_t o = ((size_t)(b * Cimg + c) * OH + oy) * OW + ox;
+        pass[o] = (pre >= 0.f && pre <= 1.f) ? 1 : 0;
+        out[o] = fminf(fmaxf(pre, 0.f), 1.f);
+    }
+}
+
+// one thread per LR pixel
+__global__ __launch_bounds__(256) void shuffle_clamp_bwd_kernel(const float* __restrict__ dout,
+                                                                 const uint8_t* __restrict__ pass, int Cimg, int H,
+                                                                 int W, int s, float* __restrict__ du, int du_ld,
+                                                                 long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int w = gid % W;
+    const int h = (gid / W) % H;
+    const int b = gid / ((long)W * H);
+    const int OW = W * s, OH = H * s;
+    float* dp = du + (size_t)gid * du_ld;
+    const int K = Cimg * s * s;
+    for (int k = 0; k < K; ++k) {
+        const int c = k / (s * s), r = k - c * s * s, i = r / s, j = r - i * s;
+        const size_t o = ((size_t)(b * Cimg + c) * OH + h * s + i) * OW + w * s + j;
+        dp[k] = pass[o] ? dout[o] : 0.f;
+    }
+    for (int k = K; k < du_ld; ++k) dp[k] = 0.f;
+}
+
+}  // namespace nvq
+
+using namespace nvq;
+
+extern "C" {
+
+int nvq_shuffle_bicubic_clamp(const float* u, int u_ld, const float* frames, int B, int T, int t_center, int Cimg,
+                              int H, int W, int s, float* out, uint8_t* pass, void* stream) {
+    NVQ_REQUIRE(s >= 1 && s <= 8 && u_ld >= Cimg * s * s && t_center >= 0 && t_center < T, "shuffle_bicubic_clamp: args");
+    const long total = (long)B * H * s * W * s;
+    const float scale = (float)(1.0 / (double)s);
+    hipLaunchKernelGGL(shuffle_bicubic_clamp_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       u_ld, frames, T, t_center, Cimg, H, W, s, scale, out, pass, total);
+    return check_launch("shuffle_bicubic_clamp");
+}
+
+int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H, int W, int s,
+                               float* du, int du_ld, void* stream) {
+    NVQ_REQUIRE(s >= 1 && s <= 8 && du_ld >= Cimg * s * s, "shuffle_clamp_backward: args");
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(shuffle_clamp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       pass, Cimg, H, W, s, du, du_ld, total);
+    return check_launch("shuffle_clamp_backward");
+}
+
+}  // extern "C"

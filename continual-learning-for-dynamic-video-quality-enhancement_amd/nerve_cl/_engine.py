@@ -1,0 +1,337 @@
+"""Kernel schedule of SuperResolutionNet forward and backward on libnvq.
+
+The op order follows the reference forward (super_resolution.py:327-391); every arithmetic
+step is a libnvq kernel launch on the current HIP stream, PyTorch only owns the buffers.
+Internal activations are fp32 NHWC.  Frames are processed in "slot" order
+[centre, other frames...] so the T feature-extractor calls of the reference become one
+batched launch per layer (BatchNorm statistics stay per frame, see nvq_bn_stats).
+
+Dense-block concatenation (torch.cat at super_resolution.py:249,252) never happens: each
+block owns one [B,H,W,F+160] buffer, layer i reads channels [0, F+32i) and writes
+[F+32i, F+32i+32); the backward accumulates into a gradient buffer of the same layout.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _nvq as K
+from ._nvq import Sl
+
+GROWTH = 32   # ResidualDenseBlock growth_rate (fixed, super_resolution.py:227)
+LAYERS = 5    # ResidualDenseBlock num_layers   (fixed, super_resolution.py:228)
+CORR_LD = 96  # 81 correlation channels stored in a 96-channel NHWC buffer (pad = 0)
+BN_EPS = 1e-5
+BN_MOM = 0.1
+
+_ws_cache: Dict[torch.device, torch.Tensor] = {}
+
+
+def workspace(device) -> torch.Tensor:
+    ws = _ws_cache.get(device)
+    if ws is None:
+        ws = torch.empty(K.wgrad_workspace_bytes() // 4 + (4 << 20), dtype=torch.float32, device=device)
+        _ws_cache[device] = ws
+    return ws
+
+
+class Geometry:
+    def __init__(self, frames: torch.Tensor, F: int, nblocks: int, scale: int):
+        self.B, self.T, self.Cimg, self.H, self.W = frames.shape
+        self.F, self.NB, self.s = F, nblocks, scale
+        self.c = self.T // 2
+        self.slots = [self.c] + [t for t in range(self.T) if t != self.c]
+        self.NI = self.T * self.B
+        self.NO = (self.T - 1) * self.B
+        self.CAT = F + GROWTH * LAYERS
+        self.Tp = K.pad4(self.T)
+        self.U = self.Cimg * scale * scale
+        self.Up = K.pad4(self.U)
+        self.R = F // 16
+
+
+def _new(dev, *shape, dtype=torch.float32, zero=False):
+    return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=dev)
+
+
+class Saved:
+    """Everything the backward needs; also the carrier of return_intermediate tensors."""
+    pass
+
+
+def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: int, scale: int,
+            training: bool, math: int = K.MATH_F32) -> "tuple[torch.Tensor, Saved]":
+    g = Geometry(frames, F, nblocks, scale)
+    dev = frames.device
+    B, T, H, W, NI, NO, c = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c
+    ws = workspace(dev)
+    sv = Saved()
+    sv.g, sv.frames, sv.training, sv.math = g, frames, training, math
+
+    # ---- feature extractor, all T frames in one batch (slot order)
+    feat0 = _new(dev, NI, H, W, F)
+    K.head_forward(frames, g.slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0)
+    aligned = _new(dev, B, H, W, T * F)
+    feat_oth = _new(dev, max(NO, 1), H, W, F)
+    sv.feat0, sv.aligned, sv.feat_oth = feat0, aligned, feat_oth
+    sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = [], [], [], [], []
+    cur = feat0
+    for k in range(3):
+        pre = f"feature_extractor.body.{k}."
+        d = _new(dev, NI, H, W, F)
+        K.dwconv_forward(cur, P[pre + "depthwise.weight"], d)
+        p = _new(dev, NI, H, W, F)
+        wp = K.conv_pack(P[pre + "pointwise.weight"], False, F)
+        K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
+        mean, invstd = _new(dev, T, F), _new(dev, T, F)
+        if training:
+            K.bn_stats(p, B, [g.slots.index(t) for t in range(T)], mean, invstd,
+                       P[pre + "bn.running_mean"], P[pre + "bn.running_var"], ws, BN_EPS, BN_MOM)
+            P[pre + "bn.num_batches_tracked"].add_(T)
+        else:
+            K.bn_eval_stats(P[pre + "bn.running_mean"], P[pre + "bn.running_var"], T, mean, invstd, BN_EPS)
+        if k < 2:
+            r = _new(dev, NI, H, W, F)
+            K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], None, Sl(r), NI)
+        else:
+            # features = relu(bn(.)) + head features; centre frame lands in its slot of `aligned`
+            r = None
+            K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], feat0,
+                            Sl(aligned, F, c * F), B, Sl(feat_oth) if NO else None)
+        sv.dws.append(d); sv.pws.append(p); sv.acts.append(r); sv.bn_mean.append(mean); sv.bn_invstd.append(invstd)
+        cur = r
+    center = Sl(aligned, F, c * F)
+
+    # ---- motion: correlation -> flow net -> warp, the T-1 reference frames batched
+    if NO:
+        corr = _new(dev, NO, H, W, CORR_LD)
+        K.correlation_forward(Sl(feat_oth), center, corr)
+        chans = [81, 128, 64, 32, 2]
+        x = Sl(corr)
+        sv.flow_acts = [corr]
+        for li, idx in enumerate((0, 2, 4, 6)):
+            w = P[f"motion_estimator.flow_net.{idx}.weight"]
+            wp = K.conv_pack(w, False, x.c)
+            last = idx == 6
+            y = _new(dev, NO, H, W, K.pad4(chans[li + 1]))
+            K.conv_forward(x, wp, P[f"motion_estimator.flow_net.{idx}.bias"], Sl(y, chans[li + 1]), 3,
+                           relu=not last, cout_store=K.pad4(chans[li + 1]), math=math)
+            sv.flow_acts.append(y)
+            x = Sl(y)
+        flow = sv.flow_acts[-1]
+        for j in range(1, T):
+            t = g.slots[j]
+            K.warp_forward(Sl(feat_oth).images((j - 1) * B, j * B), flow[(j - 1) * B:j * B], Sl(aligned, F, t * F))
+    sv.flow = sv.flow_acts[-1] if NO else None
+
+    # ---- temporal aggregation
+    a1, a2 = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
+    logits = _new(dev, B, H, W, g.Tp)
+    K.conv_forward(Sl(aligned), K.conv_pack(P["temporal_aggregator.attention.0.weight"], False, T * F),
+                   P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math)
+    K.conv_forward(Sl(a1), K.conv_pack(P["temporal_aggregator.attention.2.weight"], False, F),
+                   P["temporal_aggregator.attention.2.bias"], Sl(a2), 3, relu=True, math=math)
+    K.conv_forward(Sl(a2), K.conv_pack(P["temporal_aggregator.attention.4.weight"], False, F),
+                   P["temporal_aggregator.attention.4.bias"], Sl(logits, T), 3, cout_store=g.Tp, math=math)
+    nblk = K.tsum_blocks(H, W)
+    attn, weighted = _new(dev, B, H, W, g.Tp), _new(dev, B, H, W, F)
+    gap_partial = _new(dev, B, nblk, F)
+    K.tsum_forward(aligned, logits, T, F, attn, weighted, gap_partial)
+    gap, hid, ca = _new(dev, B, F), _new(dev, B, g.R), _new(dev, B, F)
+    w1 = P["temporal_aggregator.refine.channel_attention.fc.0.weight"]
+    w2 = P["temporal_aggregator.refine.channel_attention.fc.2.weight"]
+    w7 = P["temporal_aggregator.refine.spatial_attention.conv.weight"]
+    K.cbam_channel(gap_partial, nblk, F, g.R, B, H * W, w1, w2, gap, hid, ca)
+    sm, amax, sa = _new(dev, B, H, W, 2), _new(dev, B, H, W, dtype=torch.int32), _new(dev, B, H, W)
+    K.cbam_pool(weighted, ca, sm, amax)
+    cats = [_new(dev, B, H, W, g.CAT) for _ in range(nblocks)]
+    resout = _new(dev, B, H, W, F)
+
+    def xloc(k):  # where the input of block k / the output of block k-1 lives
+        return Sl(cats[k], F, 0) if k < nblocks else Sl(resout)
+    K.cbam_spatial_apply(weighted, ca, sm, w7, sa, xloc(0))
+    sv.a1, sv.a2, sv.attn, sv.weighted = a1, a2, attn, weighted
+    sv.gap, sv.hid, sv.ca, sv.sm, sv.amax, sv.sa, sv.nblk = gap, hid, ca, sm, amax, sa, nblk
+    sv.cats, sv.resout = cats, resout
+
+    # ---- residual dense blocks
+    for k in range(nblocks):
+        cat = cats[k]
+        for i in range(LAYERS):
+            cin = F + GROWTH * i
+            wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin)
+            K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
+                           Sl(cat, GROWTH, cin), 3, relu=True, math=math)
+        wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT)
+        K.conv_forward(Sl(cat), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
+                       res=Sl(cat, F, 0), math=math)
+
+    # ---- global fusion + upsampler tail
+    fused, gr = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
+    K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F), P["gff.0.bias"], Sl(fused), 3,
+                   relu=True, out2=Sl(gr), res=center, math=math)
+    u = _new(dev, B, H, W, g.Up)
+    K.conv_forward(Sl(fused), K.conv_pack(P["upsampler.conv.weight"], False, F), P["upsampler.conv.bias"],
+                   Sl(u, g.U), 3, cout_store=g.Up, math=math)
+    out = _new(dev, B, g.Cimg, H * scale, W * scale)
+    passmask = _new(dev, B, g.Cimg, H * scale, W * scale, dtype=torch.uint8)
+    K.shuffle_bicubic_clamp(u, frames, c, scale, out, passmask)
+    sv.fused, sv.gr, sv.passmask = fused, gr, passmask
+    sv.xloc = xloc
+    return out, sv
+
+
+def _wgrad(x: Sl, cin_w: int, dy: Sl, G: Dict[str, torch.Tensor], wname: str, bname: Optional[str], ws, ksize,
+           alpha=1.0, math=K.MATH_F32):
+    K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math)
+
+
+def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[str, torch.Tensor]) -> None:
+    """Write the gradient of every parameter into G[name] (each exactly once, overwrite)."""
+    g = sv.g
+    dev = dout.device
+    B, T, H, W, NI, NO, c, F = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c, g.F
+    math = sv.math
+    ws = workspace(dev)
+    nb = g.NB
+
+    # ---- upsampler tail
+    du = _new(dev, B, H, W, g.Up)
+    K.shuffle_clamp_backward(dout, sv.passmask, g.s, du)
+    _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", ws, 3, math=math)
+    dfeat_all = _new(dev, NI, H, W, F, zero=True)   # gradient w.r.t. the features of every frame (slot order)
+    dfeat_c = dfeat_all[:B]
+    dg = _new(dev, B, H, W, F)
+    K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F), None, Sl(dg), 3,
+                   out2=Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
+    # ---- gff
+    xN = sv.xloc(nb)
+    _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
+    dres = _new(dev, B, H, W, F)
+    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F), None, Sl(dres), 3, math=math)
+    dprev = Sl(dres)
+
+    # ---- residual dense blocks, last to first
+    dcats = [_new(dev, B, H, W, g.CAT), _new(dev, B, H, W, g.CAT)] if nb else []
+    for k in range(nb - 1, -1, -1):
+        cat = sv.cats[k]
+        dcat = dcats[k & 1]
+        pre = f"residual_blocks.{k}."
+        _wgrad(Sl(cat), g.CAT, dprev, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
+        K.conv_forward(dprev, K.conv_pack(P[pre + "lff.weight"], True, F, g.CAT), None, Sl(dcat), 1, alpha=0.2,
+                       res=dprev, mask=Sl(cat), mask_c0=F + GROWTH * (LAYERS - 1), mask_c1=g.CAT, math=math)
+        for i in range(LAYERS - 1, -1, -1):
+            cin = F + GROWTH * i
+            dy = Sl(dcat, GROWTH, cin)
+            _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
+                   math=math)
+            K.conv_forward(dy, K.conv_pack(P[pre + f"layers.{i}.0.weight"], True, GROWTH, cin), None,
+                           Sl(dcat, cin, 0), 3, accumulate=True, mask=Sl(cat) if i > 0 else None,
+                           mask_c0=cin - GROWTH, mask_c1=cin, math=math)
+        dprev = Sl(dcat, F, 0)
+
+    # ---- CBAM
+    w1 = P["temporal_aggregator.refine.channel_attention.fc.0.weight"]
+    w2 = P["temporal_aggregator.refine.channel_attention.fc.2.weight"]
+    w7 = P["temporal_aggregator.refine.spatial_attention.conv.weight"]
+    dpre = _new(dev, B, H, W)
+    K.cbam_bwd_spatial_pre(dprev, sv.weighted, sv.ca, sv.sa, dpre)
+    dsm = _new(dev, B, H, W, 2)
+    K.cbam_bwd_spatial_conv(dpre, sv.sm, w7, dsm, G["temporal_aggregator.refine.spatial_attention.conv.weight"], ws)
+    dweighted = _new(dev, B, H, W, F)
+    dca_partial = _new(dev, B, sv.nblk, F)
+    K.cbam_bwd_scale(dprev, sv.weighted, sv.ca, sv.sa, dsm, sv.amax, dweighted, dca_partial)
+    dgap_pix = _new(dev, B, F)
+    K.cbam_bwd_channel(dca_partial, sv.nblk, F, g.R, B, H * W, w1, w2, sv.gap, sv.hid, sv.ca,
+                       G["temporal_aggregator.refine.channel_attention.fc.0.weight"],
+                       G["temporal_aggregator.refine.channel_attention.fc.2.weight"], dgap_pix)
+
+    # ---- softmax-weighted sum and the attention convs
+    daligned = _new(dev, B, H, W, T * F)
+    dlogits = _new(dev, B, H, W, g.Tp)
+    K.tsum_backward(dweighted, dgap_pix, sv.aligned, sv.attn, T, F, daligned, dlogits)
+    pre = "temporal_aggregator.attention."
+    _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", ws, 3, math=math)
+    da2 = _new(dev, B, H, W, F)
+    K.conv_forward(Sl(dlogits), K.conv_pack(P[pre + "4.weight"], True, g.Tp, F), None, Sl(da2), 3,
+                   mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
+    _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
+    da1 = _new(dev, B, H, W, F)
+    K.conv_forward(Sl(da2), K.conv_pack(P[pre + "2.weight"], True, F, F), None, Sl(da1), 3,
+                   mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
+    _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
+    K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F), None, Sl(daligned), 3,
+                   accumulate=True, math=math)
+    K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
+
+    # ---- motion: warp, flow net, correlation
+    if NO:
+        dfeat_oth = dfeat_all[B:]
+        dflow = _new(dev, NO, H, W, 4)
+        for j in range(1, T):
+            t = g.slots[j]
+            lo, hi = (j - 1) * B, j * B
+            K.warp_backward(Sl(daligned, F, t * F), Sl(sv.feat_oth).images(lo, hi), sv.flow[lo:hi],
+                            Sl(dfeat_oth).images(lo, hi), dflow[lo:hi])
+        acts = sv.flow_acts          # [corr(96), f1(128), f2(64), f3(32), flow(4)]
+        chans = [81, 128, 64, 32, 2]
+        dy_t, dy_c = dflow, 2
+        for li, idx in reversed(list(enumerate((0, 2, 4, 6)))):
+            x_t = acts[li]
+            name = f"motion_estimator.flow_net.{idx}."
+            _wgrad(Sl(x_t), chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
+            cin_store = dy_t.shape[-1]
+            wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li])
+            dx_t = _new(dev, NO, H, W, x_t.shape[-1])
+            if li > 0:
+                K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
+                               mask_c1=chans[li], math=math)
+            else:
+                K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, cout_store=K.pad4(chans[li]), math=math)
+            dy_t, dy_c = dx_t, chans[li]
+        dcorr = dy_t
+        center = Sl(sv.aligned, F, c * F)
+        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True)
+        for j in range(1, T):
+            lo, hi = (j - 1) * B, j * B
+            K.correlation_backward(2, dcorr[lo:hi], Sl(sv.feat_oth).images(lo, hi), Sl(dfeat_c), True)
+
+    # ---- feature extractor (all frames batched)
+    dcur = dfeat_all
+    for k in (2, 1, 0):
+        pre = f"feature_extractor.body.{k}."
+        dp = _new(dev, NI, H, W, F)
+        K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
+                           P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
+        _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
+        dd = _new(dev, NI, H, W, F)
+        K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F), None, Sl(dd), 1, math=math)
+        xin = sv.feat0 if k == 0 else sv.acts[k - 1]
+        K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws)
+        dx = _new(dev, NI, H, W, F)
+        K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
+        dcur = dx
+    K.axpy_slice(Sl(dcur), Sl(dfeat_all))     # + the skip  feat = body(h) + h
+    K.head_wgrad(sv.frames, g.slots, dcur, sv.feat0, G["feature_extractor.head.0.weight"],
+                 G["feature_extractor.head.0.bias"], ws)
+
+
+def nhwc_to_nchw(t: torch.Tensor, c: Optional[int] = None, coff: int = 0) -> torch.Tensor:
+    c = t.shape[-1] - coff if c is None else c
+    return t[..., coff:coff + c].permute(0, 3, 1, 2).contiguous()
+
+
+def intermediates(sv: Saved) -> dict:
+    """return_intermediate payload in the reference's NCHW layout (super_resolution.py:384-389)."""
+    g = sv.g
+    feats: List[Optional[torch.Tensor]] = [None] * g.T
+    aligned: List[Optional[torch.Tensor]] = [None] * g.T
+    for j, t in enumerate(g.slots):
+        if j == 0:
+            feats[t] = nhwc_to_nchw(sv.aligned, g.F, g.c * g.F)
+        else:
+            feats[t] = nhwc_to_nchw(sv.feat_oth[(j - 1) * g.B:j * g.B])
+        aligned[t] = nhwc_to_nchw(sv.aligned, g.F, t * g.F)
+    x0 = sv.xloc(0)
+    return {"features": feats, "aligned": aligned, "aggregated": nhwc_to_nchw(x0.t, g.F, 0)}

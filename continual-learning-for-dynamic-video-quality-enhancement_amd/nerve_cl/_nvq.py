@@ -1,0 +1,425 @@
+"""ctypes binding of libnvq.so (include/nvq.h).
+
+This is the only place that touches the C ABI.  There is no CPU or PyTorch fallback:
+if the shared library is missing, or a tensor is not a contiguous fp32 HIP tensor, the
+call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("NVQ_LIB", os.path.join(os.path.dirname(_HERE), "libnvq.so"))
+
+MATH_F32 = 0
+MATH_BF16 = 1
+MAX_T = 8
+
+_lib = None
+
+vp, ci, cl, cf, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("inp", vp), ("in_ld", ci), ("in_coff", ci), ("cin", ci),
+        ("wpack", vp),
+        ("bias", vp),
+        ("out", vp), ("out_ld", ci), ("out_coff", ci), ("cout", ci),
+        ("cout_store", ci),
+        ("out2", vp), ("out2_ld", ci), ("out2_coff", ci),
+        ("res", vp), ("res_ld", ci), ("res_coff", ci), ("res_cmax", ci),
+        ("mask", vp), ("mask_ld", ci), ("mask_coff", ci), ("mask_c0", ci), ("mask_c1", ci),
+        ("n", ci), ("h", ci), ("w", ci),
+        ("ksize", ci),
+        ("relu", ci),
+        ("alpha", cf),
+        ("accumulate", ci),
+        ("math", ci),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_ld", ci), ("x_coff", ci), ("cin", ci), ("cin_w", ci),
+        ("dy", vp), ("dy_ld", ci), ("dy_coff", ci), ("cout", ci),
+        ("dw", vp), ("dbias", vp),
+        ("workspace", vp), ("workspace_bytes", sz),
+        ("n", ci), ("h", ci), ("w", ci), ("ksize", ci),
+        ("alpha", cf), ("accumulate", ci), ("math", ci),
+    ]
+
+
+_IP = C.POINTER(ci)
+
+# name -> (restype, argtypes); must list every symbol declared in include/nvq.h
+SIGNATURES = {
+    "nvq_version": (ci, []),
+    "nvq_last_error": (C.c_char_p, []),
+    "nvq_conv_pack_floats": (sz, [ci, ci, ci]),
+    "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
+    "nvq_sizeof_conv_desc": (sz, []),
+    "nvq_wgrad_workspace_bytes": (sz, []),
+    "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
+    "nvq_sizeof_wgrad_desc": (sz, []),
+    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, vp]),
+    "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
+    "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]),
+    "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
+    "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
+    "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, vp]),
+    "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
+    "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
+    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
+    "nvq_tsum_blocks": (ci, [ci, ci]),
+    "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp]),
+    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
+    "nvq_cbam_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
+    "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "nvq_cbam_bwd_spatial_pre": (ci, [vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "nvq_cbam_bwd_spatial_conv": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_cbam_bwd_scale": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "nvq_cbam_bwd_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "nvq_shuffle_clamp_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_axpy_slice": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, cl, cf, ci, vp]),
+    "nvq_colsum": (ci, [vp, ci, ci, ci, cl, cf, vp, vp, sz, ci, vp]),
+    "nvq_ewc_penalty": (ci, [vp, vp, vp, cl, cf, vp, vp, sz, vp]),
+    "nvq_ewc_penalty_grad": (ci, [vp, vp, vp, cl, cf, vp, vp, ci, vp]),
+    "nvq_fisher_accumulate": (ci, [vp, cl, vp, vp]),
+}
+
+
+def lib():
+    """Load libnvq.so once; raise loudly when it is absent (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libnvq.so not found at {LIB_PATH}: build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "nerve_cl has no CPU / PyTorch fallback for the super-resolution hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        assert l.nvq_sizeof_conv_desc() == C.sizeof(ConvDesc), "nvq_conv_desc layout mismatch"
+        assert l.nvq_sizeof_wgrad_desc() == C.sizeof(WgradDesc), "nvq_wgrad_desc layout mismatch"
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {lib().nvq_last_error().decode()}")
+
+
+def stream() -> vp:
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t: torch.Tensor, what: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} lives on {t.device}: the nerve_cl super-resolution path runs only as HIP kernels "
+            "on an AMD GPU (move the model and its inputs to 'cuda'); there is no CPU fallback.")
+
+
+def ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
+    """Device address of element `off` of a contiguous fp32/int32/uint8 tensor (None passes NULL)."""
+    if t is None:
+        return None
+    require_device(t)
+    assert t.is_contiguous(), "libnvq needs contiguous tensors"
+    return t.data_ptr() + off * t.element_size()
+
+
+def int_array(vals: Sequence[int]):
+    return (ci * len(vals))(*vals)
+
+
+class Sl:
+    """A channel slice of an fp32 NHWC buffer: tensor [N,H,W,ld], channels [coff, coff+c)."""
+
+    __slots__ = ("t", "ld", "coff", "c")
+
+    def __init__(self, t: torch.Tensor, c: Optional[int] = None, coff: int = 0):
+        assert t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()
+        self.t, self.ld, self.coff = t, t.shape[-1], coff
+        self.c = t.shape[-1] - coff if c is None else c
+        assert self.coff + self.c <= self.ld
+
+    @property
+    def n(self):
+        return self.t.shape[0]
+
+    def images(self, lo: int, hi: int) -> "Sl":
+        return Sl(self.t[lo:hi], self.c, self.coff)
+
+    def base(self) -> int:
+        """address of channel `coff` of pixel 0"""
+        return ptr(self.t, self.coff)
+
+
+def wgrad_workspace_bytes() -> int:
+    return int(lib().nvq_wgrad_workspace_bytes())
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+# ----------------------------------------------------------------------------- convolution
+def conv_pack(w: torch.Tensor, transpose: bool, cin_store: int, cout_keep: Optional[int] = None) -> torch.Tensor:
+    """Pack a PyTorch conv weight [Cout, Cin, k, k] for nvq_conv_forward."""
+    cout_w, cin_w, k, _ = w.shape
+    keep = (cin_w if cout_keep is None else cout_keep) if transpose else cout_w
+    n = lib().nvq_conv_pack_floats(keep, cin_store, k)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib().nvq_conv_pack(ptr(w.contiguous()), cout_w, cin_w, k, int(transpose), cin_store,
+                              keep if transpose else 0, ptr(wp), stream()), "nvq_conv_pack")
+    return wp
+
+
+def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl, ksize: int, *,
+                 relu: bool = False, alpha: float = 1.0, accumulate: bool = False,
+                 cout_store: Optional[int] = None, out2: Optional[Sl] = None,
+                 res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
+                 mask_c1: int = 0, math: int = MATH_F32) -> None:
+    n, h, w, _ = x.t.shape
+    assert out.t.shape[:3] == x.t.shape[:3]
+    d = ConvDesc()
+    d.inp, d.in_ld, d.in_coff, d.cin = ptr(x.t), x.ld, x.coff, x.c
+    d.wpack = ptr(wpack)
+    d.bias = ptr(bias)
+    d.out, d.out_ld, d.out_coff, d.cout = ptr(out.t), out.ld, out.coff, out.c
+    d.cout_store = out.c if cout_store is None else cout_store
+    if out2 is not None:
+        d.out2, d.out2_ld, d.out2_coff = ptr(out2.t), out2.ld, out2.coff
+    if res is not None:
+        d.res, d.res_ld, d.res_coff, d.res_cmax = ptr(res.t), res.ld, res.coff, res.c
+    if mask is not None:
+        d.mask, d.mask_ld, d.mask_coff, d.mask_c0, d.mask_c1 = ptr(mask.t), mask.ld, mask.coff, mask_c0, mask_c1
+    d.n, d.h, d.w, d.ksize = n, h, w, ksize
+    d.relu, d.alpha, d.accumulate, d.math = int(relu), alpha, int(accumulate), math
+    check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
+
+
+def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torch.Tensor],
+               ws: torch.Tensor, ksize: int, *, alpha: float = 1.0, accumulate: bool = False,
+               math: int = MATH_F32) -> None:
+    n, h, w, _ = x.t.shape
+    d = WgradDesc()
+    d.x, d.x_ld, d.x_coff, d.cin, d.cin_w = ptr(x.t), x.ld, x.coff, x.c, cin_w
+    d.dy, d.dy_ld, d.dy_coff, d.cout = ptr(dy.t), dy.ld, dy.coff, dy.c
+    d.dw, d.dbias = ptr(dw), ptr(dbias)
+    d.workspace, d.workspace_bytes = ptr(ws), ws.numel() * ws.element_size()
+    d.n, d.h, d.w, d.ksize = n, h, w, ksize
+    d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
+    check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
+
+
+# ----------------------------------------------------------------------------- feature extractor
+def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: torch.Tensor) -> None:
+    B, T, Cin, H, W = frames.shape
+    F = weight.shape[0]
+    check(lib().nvq_head_forward(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(weight),
+                                 ptr(bias), F, ptr(out), out.shape[-1], stream()), "nvq_head_forward")
+
+
+def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, dbias, ws, accumulate=False):
+    B, T, Cin, H, W = frames.shape
+    F = dweight.shape[0]
+    check(lib().nvq_head_wgrad(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(dout),
+                               dout.shape[-1], ptr(act), act.shape[-1], F, ptr(dweight), ptr(dbias), ptr(ws),
+                               ws.numel() * 4, int(accumulate), stream()), "nvq_head_wgrad")
+
+
+def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False):
+    N, H, W, ld = x.shape
+    Cc = weight.shape[0]
+    check(lib().nvq_dwconv_forward(ptr(x), ld, ptr(weight), Cc, ptr(out), out.shape[-1], N, H, W, int(flip),
+                                   stream()), "nvq_dwconv_forward")
+
+
+def dwconv_wgrad(x: torch.Tensor, dy: torch.Tensor, dweight, ws, accumulate=False):
+    N, H, W, ld = x.shape
+    Cc = dweight.shape[0]
+    check(lib().nvq_dwconv_wgrad(ptr(x), ld, ptr(dy), dy.shape[-1], Cc, N, H, W, ptr(dweight), ptr(ws),
+                                 ws.numel() * 4, int(accumulate), stream()), "nvq_dwconv_wgrad")
+
+
+def bn_stats(x: torch.Tensor, group_images: int, order: Sequence[int], mean, invstd, rmean, rvar, ws,
+             eps=1e-5, momentum=0.1):
+    N, H, W, ld = x.shape
+    Cc = mean.shape[-1]
+    check(lib().nvq_bn_stats(ptr(x), ld, Cc, N, group_images, H, W, eps, momentum, int_array(order), ptr(mean),
+                             ptr(invstd), ptr(rmean), ptr(rvar), ptr(ws), ws.numel() * 4, stream()),
+          "nvq_bn_stats")
+
+
+def bn_eval_stats(rmean, rvar, G: int, mean, invstd, eps=1e-5):
+    check(lib().nvq_bn_eval_stats(ptr(rmean), ptr(rvar), rmean.numel(), G, eps, ptr(mean), ptr(invstd), stream()),
+          "nvq_bn_eval_stats")
+
+
+def bn_apply_relu(x: torch.Tensor, group_images: int, mean, invstd, gamma, beta, res: Optional[torch.Tensor],
+                  outA: Sl, split_images: int, outB: Optional[Sl] = None):
+    N, H, W, ld = x.shape
+    Cc = gamma.numel()
+    check(lib().nvq_bn_apply_relu(ptr(x), ld, Cc, N, group_images, H, W, ptr(mean), ptr(invstd), ptr(gamma),
+                                  ptr(beta), ptr(res), res.shape[-1] if res is not None else 0, ptr(outA.t),
+                                  outA.ld, outA.coff, split_images, ptr(outB.t) if outB else None,
+                                  outB.ld if outB else 0, outB.coff if outB else 0, stream()),
+          "nvq_bn_apply_relu")
+
+
+def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean, invstd, gamma, beta,
+                     training: bool, dx: torch.Tensor, dgamma, dbeta, ws, accumulate=False):
+    N, H, W, ld = x.shape
+    Cc = gamma.numel()
+    check(lib().nvq_bn_relu_backward(ptr(dy), dy.shape[-1], ptr(x), ld, Cc, N, group_images, H, W, ptr(mean),
+                                     ptr(invstd), ptr(gamma), ptr(beta), int(training), ptr(dx), dx.shape[-1],
+                                     ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), stream()),
+          "nvq_bn_relu_backward")
+
+
+# ----------------------------------------------------------------------------- motion
+def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor):
+    N, H, W, _ = x1.t.shape
+    check(lib().nvq_correlation_forward(x1.base(), x1.ld, x2.base(), x2.ld, x2.n, x1.c, N, H, W, ptr(out),
+                                        out.shape[-1], stream()), "nvq_correlation_forward")
+
+
+def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool):
+    N, H, W, ld = dcorr.shape
+    check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N, H, W,
+                                         ptr(dx.t), dx.ld, dx.coff, int(accumulate), stream()),
+          "nvq_correlation_backward")
+
+
+def warp_forward(feat: Sl, flow: torch.Tensor, out: Sl):
+    N, H, W, _ = feat.t.shape
+    check(lib().nvq_warp_forward(feat.base(), feat.ld, ptr(flow), flow.shape[-1], feat.c, N, H, W, ptr(out.t),
+                                 out.ld, out.coff, stream()), "nvq_warp_forward")
+
+
+def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torch.Tensor):
+    N, H, W, _ = feat.t.shape
+    check(lib().nvq_warp_backward(ptr(dout.t), dout.ld, dout.coff, feat.base(), feat.ld, ptr(flow),
+                                  flow.shape[-1], feat.c, N, H, W, dfeat.base(), dfeat.ld, ptr(dflow),
+                                  dflow.shape[-1], stream()), "nvq_warp_backward")
+
+
+# ----------------------------------------------------------------------------- aggregation
+def tsum_blocks(H: int, W: int) -> int:
+    return int(lib().nvq_tsum_blocks(H, W))
+
+
+def tsum_forward(aligned: torch.Tensor, logits: torch.Tensor, T: int, Cc: int, attn, weighted, gap_partial):
+    N, H, W, ld = aligned.shape
+    check(lib().nvq_tsum_forward(ptr(aligned), ld, ptr(logits), logits.shape[-1], T, Cc, N, H, W, ptr(attn),
+                                 attn.shape[-1], ptr(weighted), weighted.shape[-1], ptr(gap_partial), stream()),
+          "nvq_tsum_forward")
+
+
+def tsum_backward(dweighted, dgap_pix, aligned, attn, T: int, Cc: int, daligned, dlogits):
+    N, H, W, ld = aligned.shape
+    check(lib().nvq_tsum_backward(ptr(dweighted), dweighted.shape[-1], ptr(dgap_pix), ptr(aligned), ld, ptr(attn),
+                                  attn.shape[-1], T, Cc, N, H, W, ptr(daligned), daligned.shape[-1], ptr(dlogits),
+                                  dlogits.shape[-1], stream()), "nvq_tsum_backward")
+
+
+def cbam_channel(gap_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca):
+    check(lib().nvq_cbam_channel(ptr(gap_partial), nblk, Cc, R, N, HW, ptr(w1), ptr(w2), ptr(gap), ptr(hid),
+                                 ptr(ca), stream()), "nvq_cbam_channel")
+
+
+def cbam_pool(x: torch.Tensor, ca, sm, amax):
+    N, H, W, ld = x.shape
+    check(lib().nvq_cbam_pool(ptr(x), ld, ptr(ca), ca.shape[-1], N, H, W, ptr(sm), ptr(amax), stream()),
+          "nvq_cbam_pool")
+
+
+def cbam_spatial_apply(x: torch.Tensor, ca, sm, w7, sa, out: Sl):
+    N, H, W, ld = x.shape
+    check(lib().nvq_cbam_spatial_apply(ptr(x), ld, ptr(ca), ptr(sm), ptr(w7), ca.shape[-1], N, H, W, ptr(sa),
+                                       ptr(out.t), out.ld, out.coff, stream()), "nvq_cbam_spatial_apply")
+
+
+def cbam_bwd_spatial_pre(dout: Sl, x: torch.Tensor, ca, sa, dpre):
+    N, H, W, ld = x.shape
+    check(lib().nvq_cbam_bwd_spatial_pre(ptr(dout.t), dout.ld, dout.coff, ptr(x), ld, ptr(ca), ptr(sa),
+                                         ca.shape[-1], N, H, W, ptr(dpre), stream()), "nvq_cbam_bwd_spatial_pre")
+
+
+def cbam_bwd_spatial_conv(dpre, sm, w7, dsm, dw7, ws, accumulate=False):
+    N, H, W = dpre.shape[:3]
+    check(lib().nvq_cbam_bwd_spatial_conv(ptr(dpre), ptr(sm), ptr(w7), N, H, W, ptr(dsm), ptr(dw7), ptr(ws),
+                                          ws.numel() * 4, int(accumulate), stream()), "nvq_cbam_bwd_spatial_conv")
+
+
+def cbam_bwd_scale(dout: Sl, x: torch.Tensor, ca, sa, dsm, amax, dx: torch.Tensor, dca_partial):
+    N, H, W, ld = x.shape
+    check(lib().nvq_cbam_bwd_scale(ptr(dout.t), dout.ld, dout.coff, ptr(x), ld, ptr(ca), ptr(sa), ptr(dsm),
+                                   ptr(amax), ca.shape[-1], N, H, W, ptr(dx), dx.shape[-1], ptr(dca_partial),
+                                   stream()), "nvq_cbam_bwd_scale")
+
+
+def cbam_bwd_channel(dca_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca, dw1, dw2, dgap_pix, accumulate=False):
+    check(lib().nvq_cbam_bwd_channel(ptr(dca_partial), nblk, Cc, R, N, HW, ptr(w1), ptr(w2), ptr(gap), ptr(hid),
+                                     ptr(ca), ptr(dw1), ptr(dw2), ptr(dgap_pix), int(accumulate), stream()),
+          "nvq_cbam_bwd_channel")
+
+
+# ----------------------------------------------------------------------------- upsampler tail
+def shuffle_bicubic_clamp(u: torch.Tensor, frames: torch.Tensor, t_center: int, s: int, out, passmask):
+    B, T, Cimg, H, W = frames.shape
+    check(lib().nvq_shuffle_bicubic_clamp(ptr(u), u.shape[-1], ptr(frames), B, T, t_center, Cimg, H, W, s,
+                                          ptr(out), ptr(passmask), stream()), "nvq_shuffle_bicubic_clamp")
+
+
+def shuffle_clamp_backward(dout: torch.Tensor, passmask, s: int, du: torch.Tensor):
+    B, Cimg, OH, OW = dout.shape
+    check(lib().nvq_shuffle_clamp_backward(ptr(dout), ptr(passmask), B, Cimg, OH // s, OW // s, s, ptr(du),
+                                           du.shape[-1], stream()), "nvq_shuffle_clamp_backward")
+
+
+# ----------------------------------------------------------------------------- helpers
+def axpy_slice(dst: Sl, src: Sl, alpha: float = 1.0, accumulate: bool = True, mask: Optional[Sl] = None):
+    npix = dst.t.shape[0] * dst.t.shape[1] * dst.t.shape[2]
+    assert dst.c == src.c
+    check(lib().nvq_axpy_slice(ptr(dst.t), dst.ld, dst.coff, ptr(src.t), src.ld, src.coff,
+                               ptr(mask.t) if mask else None, mask.ld if mask else 0, mask.coff if mask else 0,
+                               dst.c, npix, alpha, int(accumulate), stream()), "nvq_axpy_slice")
+
+
+def colsum(x: Sl, out: torch.Tensor, ws, alpha=1.0, accumulate=False):
+    npix = x.t.shape[0] * x.t.shape[1] * x.t.shape[2]
+    check(lib().nvq_colsum(ptr(x.t), x.ld, x.coff, x.c, npix, alpha, ptr(out), ptr(ws), ws.numel() * 4,
+                           int(accumulate), stream()), "nvq_colsum")
+
+
+# ----------------------------------------------------------------------------- EWC
+def ewc_penalty(theta, star, fisher, lam: float, out, ws):
+    check(lib().nvq_ewc_penalty(ptr(theta), ptr(star), ptr(fisher), theta.numel(), lam, ptr(out), ptr(ws),
+                                ws.numel() * 4, stream()), "nvq_ewc_penalty")
+
+
+def ewc_penalty_grad(theta, star, fisher, lam: float, scale_dev, grad, accumulate: bool):
+    check(lib().nvq_ewc_penalty_grad(ptr(theta), ptr(star), ptr(fisher), theta.numel(), lam, ptr(scale_dev),
+                                     ptr(grad), int(accumulate), stream()), "nvq_ewc_penalty_grad")
+
+
+def fisher_accumulate(grad, fisher):
+    check(lib().nvq_fisher_accumulate(ptr(grad), grad.numel(), ptr(fisher), stream()), "nvq_fisher_accumulate")

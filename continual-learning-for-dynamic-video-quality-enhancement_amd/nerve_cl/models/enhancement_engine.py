@@ -1,0 +1,114 @@
+"""EnhancementEngine: the dict-returning wrapper ("plugin surface") around the SR net.
+
+Mirrors the reference's interface (nerve_cl/models/enhancement_engine.py:18-292):
+``EnhancementConfig`` fields and defaults, ``EnhancementEngine(config)`` attributes
+(``config``, ``frame_recovery``, ``super_resolution``, ``enhancement_strength``) and
+``forward(frames, center_idx, corruption_mask, enhancement_strength) -> dict`` with keys
+'enhanced' (always), 'super_resolved', 'recovered'.  Only the super-resolution branch is
+on the MI355X hot path; the frame-recovery head is the first "next" row of SURVEY.md 8f.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from nerve_cl.models.super_resolution import SuperResolutionNet
+
+
+@dataclass
+class EnhancementConfig:
+    """Same fields and defaults as the reference (enhancement_engine.py:22-37)."""
+    frame_recovery_enabled: bool = True
+    recovery_base_channels: int = 64
+    recovery_temporal_window: int = 2
+    super_resolution_enabled: bool = True
+    scale_factor: int = 2
+    sr_num_features: int = 64
+    sr_num_residual_blocks: int = 8
+    sr_temporal_window: int = 1
+    use_lightweight_sr: bool = False
+    enhancement_mode: str = "sequential"
+    upscale_first: bool = False
+
+
+class EnhancementEngine(nn.Module):
+    def __init__(self, config: Optional[EnhancementConfig] = None):
+        super().__init__()
+        self.config = config or EnhancementConfig()
+        # The inpainting head is not consumed by the SR output in the reference either
+        # (enhancement_engine.py:143-148 feeds the ORIGINAL frames to SR); it is not built yet.
+        self.frame_recovery = None
+        self._frame_recovery_requested = bool(self.config.frame_recovery_enabled)
+        if self.config.super_resolution_enabled:
+            if self.config.use_lightweight_sr:
+                raise NotImplementedError("use_lightweight_sr is outside the MI355X hot path built so far")
+            self.super_resolution = SuperResolutionNet(
+                scale_factor=self.config.scale_factor,
+                num_features=self.config.sr_num_features,
+                num_residual_blocks=self.config.sr_num_residual_blocks,
+                temporal_window=self.config.sr_temporal_window,
+            )
+        else:
+            self.super_resolution = None
+        self.enhancement_strength = nn.Parameter(torch.ones(1))
+
+    def forward(self, frames: torch.Tensor, center_idx: Optional[int] = None,
+                corruption_mask: Optional[torch.Tensor] = None,
+                enhancement_strength: Optional[float] = None) -> Dict[str, torch.Tensor]:
+        B, T, C, H, W = frames.shape
+        if center_idx is None:
+            center_idx = T // 2
+        results: Dict[str, torch.Tensor] = {}
+        current = frames[:, center_idx]
+        if self._frame_recovery_requested and corruption_mask is not None:
+            # same guard as the reference (:130-131): recovery only runs on a non-empty mask
+            if bool(corruption_mask.sum() > 0):
+                raise NotImplementedError(
+                    "FrameRecoveryNet is not built yet (SURVEY.md 8f row 1); pass corruption_mask=None "
+                    "or construct the engine with frame_recovery_enabled=False")
+        if self.super_resolution is not None:
+            w = self.config.sr_temporal_window
+            lo, hi = max(0, center_idx - w), min(T, center_idx + w + 1)
+            sr_frames = frames[:, lo:hi]
+            need = 2 * w + 1
+            if sr_frames.shape[1] < need:   # right-pad by repeating the last frame (:152-158)
+                sr_frames = torch.cat(
+                    [sr_frames, sr_frames[:, -1:].expand(-1, need - sr_frames.shape[1], -1, -1, -1)], dim=1)
+            current = self.super_resolution(sr_frames)
+            results["super_resolved"] = current
+        strength = enhancement_strength if enhancement_strength is not None else self.enhancement_strength.item()
+        if strength < 1.0 and "super_resolved" in results:
+            raise NotImplementedError("strength < 1 bicubic blending is a 'next' row (SURVEY.md 8f row 2)")
+        results["enhanced"] = current
+        return results
+
+    def get_model_info(self) -> Dict[str, Any]:
+        info: Dict[str, Any] = {
+            "config": {
+                "frame_recovery_enabled": self.config.frame_recovery_enabled,
+                "super_resolution_enabled": self.config.super_resolution_enabled,
+                "scale_factor": self.config.scale_factor,
+                "use_lightweight_sr": self.config.use_lightweight_sr,
+            },
+            "parameters": {
+                "total": sum(p.numel() for p in self.parameters()),
+                "trainable": sum(p.numel() for p in self.parameters() if p.requires_grad),
+            },
+        }
+        if self.super_resolution is not None:
+            info["parameters"]["super_resolution"] = self.super_resolution.get_num_parameters()
+        return info
+
+    def set_enhancement_mode(self, mode: str) -> None:
+        if mode == "full":
+            self.config.frame_recovery_enabled, self.config.super_resolution_enabled = True, True
+        elif mode == "recovery_only":
+            self.config.frame_recovery_enabled, self.config.super_resolution_enabled = True, False
+        elif mode == "sr_only":
+            self.config.frame_recovery_enabled, self.config.super_resolution_enabled = False, True
+        elif mode == "lightweight":
+            self.config.frame_recovery_enabled, self.config.super_resolution_enabled = False, True
+            self.config.use_lightweight_sr = True

@@ -1,0 +1,16 @@
+"""Parameter-holder layers of the SR hot path (see efficient_layers.py)."""
+from nerve_cl.models.layers.efficient_layers import (
+    DepthwiseSeparableConv,
+    PixelShuffleUpsampler,
+    ChannelAttention,
+    SpatialAttention,
+    CBAM,
+    LiteFlowNetCorrelation,
+    Stack,
+    Act,
+)
+
+__all__ = [
+    "DepthwiseSeparableConv", "PixelShuffleUpsampler", "ChannelAttention", "SpatialAttention",
+    "CBAM", "LiteFlowNetCorrelation", "Stack", "Act",
+]

@@ -1,0 +1,206 @@
+"""SuperResolutionNet on MI355X: the reference's module surface over libnvq HIP kernels.
+
+Constructor, attribute names, ``state_dict`` keys and forward signature follow the
+reference (nerve_cl/models/super_resolution.py:256-431) so that
+``experiments/train_baseline.py`` / ``train_continual.py`` run unchanged.  The whole
+forward is ONE autograd node: its forward launches the kernel schedule of
+``nerve_cl._engine.forward`` and its backward the hand-written gradient schedule, writing
+every parameter gradient into one flat bucket (which is what a data-parallel run
+all-reduces over RCCL, see ``nerve_cl.parallel``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from nerve_cl import _engine, _nvq
+from nerve_cl.models.layers import (
+    CBAM,
+    DepthwiseSeparableConv,
+    LiteFlowNetCorrelation,
+    PixelShuffleUpsampler,
+    Stack,
+    Act,
+)
+from nerve_cl.models.layers.efficient_layers import _Holder
+
+
+class FeatureExtractor(_Holder):
+    """head conv3x3+ReLU, three depthwise-separable blocks, skip (reference :22-54)."""
+
+    def __init__(self, in_channels: int = 3, num_features: int = 64):
+        super().__init__()
+        self.head = Stack(nn.Conv2d(in_channels, num_features, 3, 1, 1), Act())
+        self.body = Stack(*[DepthwiseSeparableConv(num_features, num_features) for _ in range(3)])
+
+
+class MotionEstimator(_Holder):
+    """correlation(d=4) + flow_net 81->128->64->32->2 (reference :57-101)."""
+
+    def __init__(self, in_channels: int = 64):
+        super().__init__()
+        self.correlation = LiteFlowNetCorrelation(max_displacement=4)
+        self.flow_net = Stack(nn.Conv2d(81, 128, 3, 1, 1), Act(), nn.Conv2d(128, 64, 3, 1, 1), Act(),
+                              nn.Conv2d(64, 32, 3, 1, 1), Act(), nn.Conv2d(32, 2, 3, 1, 1))
+
+
+class TemporalAggregator(_Holder):
+    """attention convs T*F->F->F->T + softmax-weighted sum + CBAM (reference :146-209)."""
+
+    def __init__(self, num_features: int = 64, num_frames: int = 3):
+        super().__init__()
+        self.num_frames = num_frames
+        self.attention = Stack(nn.Conv2d(num_features * num_frames, num_features, 3, 1, 1), Act(),
+                               nn.Conv2d(num_features, num_features, 3, 1, 1), Act(),
+                               nn.Conv2d(num_features, num_frames, 3, 1, 1), Act())
+        self.refine = CBAM(num_features)
+
+
+class ResidualDenseBlock(_Holder):
+    """five dense 3x3 layers (growth 32) + 1x1 fusion, 0.2 residual scaling (reference :212-253)."""
+
+    def __init__(self, num_features: int = 64, growth_rate: int = 32, num_layers: int = 5):
+        super().__init__()
+        if (growth_rate, num_layers) != (_engine.GROWTH, _engine.LAYERS):
+            raise NotImplementedError("libnvq implements growth_rate=32, num_layers=5 (the values the SR net uses)")
+        self.layers = nn.ModuleList()
+        ch = num_features
+        for _ in range(num_layers):
+            self.layers.append(Stack(nn.Conv2d(ch, growth_rate, 3, 1, 1), Act()))
+            ch += growth_rate
+        self.lff = nn.Conv2d(ch, num_features, 1)
+
+
+class _SRFunction(torch.autograd.Function):
+    """One autograd node for the whole network."""
+
+    @staticmethod
+    def forward(ctx, net: "SuperResolutionNet", frames: torch.Tensor, want_inter: bool, *params):
+        P = net._tensor_dict()
+        out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        ctx.net = net
+        ctx.sv = sv if need_grad else None
+        net._last_intermediates = _engine.intermediates(sv) if want_inter else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net, sv = ctx.net, ctx.sv
+        if sv is None:
+            raise RuntimeError("SuperResolutionNet backward called without saved forward state")
+        names = net._param_names
+        flat, views = net._new_grad_bucket()
+        _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
+        ctx.sv = None
+        hook = net._grad_bucket_hook
+        if hook is not None:
+            hook(flat)           # data-parallel all-reduce of the whole bucket (nerve_cl.parallel)
+        net._last_grad_bucket = flat
+        return (None, None, None) + tuple(views[n] for n in names)
+
+
+class SuperResolutionNet(nn.Module):
+    """Temporal super-resolution network (reference :256-431), MI355X-native.
+
+    Args (same as the reference):
+        in_channels, scale_factor (2/3/4), num_features (power of two >= 16),
+        num_residual_blocks, temporal_window (T = 2*window + 1 frames).
+    """
+
+    def __init__(self, in_channels: int = 3, scale_factor: int = 2, num_features: int = 64,
+                 num_residual_blocks: int = 8, temporal_window: int = 1):
+        super().__init__()
+        if num_features < 16 or num_features & (num_features - 1) or num_features > 256:
+            raise NotImplementedError("libnvq needs num_features to be a power of two in [16, 256]")
+        if 2 * temporal_window + 1 > _nvq.MAX_T:
+            raise NotImplementedError(f"libnvq supports at most {_nvq.MAX_T} frames")
+        self.scale_factor = scale_factor
+        self.temporal_window = temporal_window
+        self.num_frames = 2 * temporal_window + 1
+        self._F, self._NB, self._Cimg = num_features, num_residual_blocks, in_channels
+
+        self.feature_extractor = FeatureExtractor(in_channels, num_features)
+        self.motion_estimator = MotionEstimator(num_features)
+        self.temporal_aggregator = TemporalAggregator(num_features, self.num_frames)
+        self.residual_blocks = Stack(*[ResidualDenseBlock(num_features) for _ in range(num_residual_blocks)])
+        self.gff = Stack(nn.Conv2d(num_features, num_features, 3, 1, 1), Act())
+        self.upsampler = PixelShuffleUpsampler(num_features, scale_factor, in_channels)
+        self.bicubic_upsample = Act()   # nn.Upsample(bicubic) in the reference; fused into the tail kernel
+
+        self.math_mode = _nvq.MATH_F32
+        self._param_names: List[str] = [n for n, _ in self.named_parameters()]
+        self._grad_bucket_hook = None
+        self._last_intermediates = None
+        self._last_grad_bucket = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _tensor_dict(self) -> Dict[str, torch.Tensor]:
+        d = {n: p.data for n, p in self.named_parameters()}
+        d.update({n: b for n, b in self.named_buffers()})
+        return d
+
+    def _bucket_layout(self) -> "Tuple[Dict[str, Tuple[int, int]], int]":
+        """{name: (offset, numel)} with 16-byte aligned offsets, total floats."""
+        lay, off = {}, 0
+        for n, p in self.named_parameters():
+            lay[n] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4
+        return lay, off
+
+    def _new_grad_bucket(self):
+        lay, total = self._bucket_layout()
+        dev = next(self.parameters()).device
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        shapes = {n: p.shape for n, p in self.named_parameters()}
+        views = {n: flat[o:o + k].view(shapes[n]) for n, (o, k) in lay.items()}
+        return flat, views
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, lr_frames: torch.Tensor, return_intermediate: bool = False):
+        """(B,T,C,H,W) low-resolution clip -> (B,C,H*s,W*s) super-resolved centre frame."""
+        B, T, C, H, W = lr_frames.shape
+        _nvq.require_device(lr_frames, "lr_frames")
+        _nvq.require_device(next(self.parameters()), "SuperResolutionNet parameters")
+        if T != self.num_frames:
+            raise RuntimeError(f"expected {self.num_frames} frames (temporal_window={self.temporal_window}), got {T}")
+        if C != self._Cimg:
+            raise RuntimeError(f"expected {self._Cimg} image channels, got {C}")
+        if H < 2 or W < 2:
+            raise RuntimeError("frames must be at least 2x2 (grid_sample normalisation divides by size-1)")
+        frames = lr_frames.detach().to(torch.float32).contiguous()
+        params = [p for _, p in self.named_parameters()]
+        out = _SRFunction.apply(self, frames, bool(return_intermediate), *params)
+        if return_intermediate:
+            inter, self._last_intermediates = self._last_intermediates, None
+            return out, inter
+        return out
+
+    def forward_single(self, lr_frame: torch.Tensor) -> torch.Tensor:
+        """Upscale one frame: it is repeated T times (reference :393-405)."""
+        return self.forward(lr_frame.unsqueeze(1).expand(-1, self.num_frames, -1, -1, -1))
+
+    def get_num_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def get_flops(self, input_size: Tuple[int, int] = (128, 128)) -> int:
+        """The reference's closed-form estimate, reproduced verbatim including its fixed
+        F=64 / 8 blocks (reference :411-431)."""
+        H, W = input_size
+        C, F = 3, 64
+        flops = H * W * C * F * 9
+        flops += H * W * F * 81 * (self.num_frames - 1)
+        flops += H * W * F * F * 9 * 8
+        flops += H * W * F * (C * self.scale_factor * self.scale_factor) * 9
+        return flops
+
+
+class LightweightSuperResolution(nn.Module):
+    """Single-frame variant of the reference (:434-470).  Not on the accelerated path yet."""
+
+    def __init__(self, scale_factor: int = 2):
+        super().__init__()
+        raise NotImplementedError(
+            "LightweightSuperResolution is outside the MI355X hot path built so far (SURVEY.md 8f row 2)")

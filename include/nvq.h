@@ -1,0 +1,278 @@
+/*
+ * nvq.h — C ABI of libnvq.so, the MI355X (gfx950) kernels behind
+ * nerve_cl.models.SuperResolutionNet forward/backward and nerve_cl.continual.EWC.
+ *
+ * The reference (manikya7022/Continual-Learning-for-Dynamic-Video-Quality-Enhancement)
+ * has no native / FFI boundary: its hot path is a chain of torch.nn calls.  Each entry
+ * point below therefore names the reference torch call(s) it replaces (file:line,
+ * relative to the reference checkout).  The Python host that binds these symbols is
+ * nerve_cl/_nvq.py (ctypes); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator);
+ *    the library never allocates, frees, synchronises or changes device: calls are
+ *    stream-ordered on `stream` (a hipStream_t passed as void*) and graph-capturable.
+ *  - activations are fp32 "NHWC with leading dimension": image n, pixel (y,x), channel c
+ *    lives at base[((n*H + y)*W + x)*ld + coff + c].  A channel slice of a wider buffer
+ *    (dense-block concat, frame-major aligned stack) is addressed by (base, ld, coff);
+ *    ld and coff are in elements.  Tensors at the module boundary (frames in, SR frame
+ *    out, parameters and their gradients) are fp32 NCHW / PyTorch layout.
+ *  - return value: 0 on success, a negative NVQ_E* code otherwise; nvq_last_error()
+ *    returns a thread-local description.  Nothing throws.
+ */
+#ifndef NVQ_H
+#define NVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVQ_OK 0
+#define NVQ_EINVAL (-1)   /* bad argument / unsupported shape */
+#define NVQ_ELAUNCH (-2)  /* hipLaunch / hipGetLastError failure */
+#define NVQ_EWORKSPACE (-3)
+
+#define NVQ_MATH_F32 0    /* v_mfma_f32_16x16x4_f32: exact fp32 products and sums */
+#define NVQ_MATH_BF16 1   /* operands rounded to bf16 in LDS, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+
+#define NVQ_MAX_T 8
+
+int nvq_version(void);
+const char* nvq_last_error(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Dense k x k (k = 1 or 3), stride 1, zero "same" padding, cross-correlation
+ * convention: replaces nn.Conv2d forward and, with a transposed pack, its input
+ * gradient.  Reference call sites: flow_net super_resolution.py:74-82, attention
+ * :168-175, ResidualDenseBlock :236-253, gff :308-311, upsampler conv
+ * efficient_layers.py:94-100, pointwise :49-56. */
+
+/* Packed-weight size in floats for a conv with `cout` outputs reading `cin_store`
+ * stored input channels (cin_store % 4 == 0). */
+size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize);
+
+/* w: PyTorch layout [cout_w][cin_w][k][k].
+ * transpose == 0: forward pack; output channels = cout_w, input channels = cin_w
+ *                 (zero-padded up to cin_store).
+ * transpose == 1: input-gradient pack; output channels = cin_w (only the first
+ *                 `cout_keep` are kept), input channels = cout_w (padded to cin_store),
+ *                 taps flipped. */
+int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpose,
+                  int cin_store, int cout_keep, float* wpack, void* stream);
+
+typedef struct nvq_conv_desc {
+    const float* in;  int in_ld;  int in_coff;  int cin;       /* cin % 4 == 0 stored channels */
+    const float* wpack;                                          /* from nvq_conv_pack */
+    const float* bias;                                           /* [cout] or NULL */
+    float* out;       int out_ld; int out_coff; int cout;      /* real output channels */
+    int cout_store;                                              /* >= cout: channels [cout,cout_store) are written as the epilogue of a zero accumulator */
+    float* out2;      int out2_ld; int out2_coff;               /* optional: value before residual/accumulate/mask */
+    const float* res; int res_ld; int res_coff; int res_cmax;   /* residual added to out channels < res_cmax */
+    const float* mask; int mask_ld; int mask_coff; int mask_c0; int mask_c1; /* out channels in [c0,c1) are zeroed where mask <= 0 */
+    int n, h, w;
+    int ksize;        /* 1 or 3 */
+    int relu;         /* max(.,0) after bias */
+    float alpha;      /* scale after relu */
+    int accumulate;   /* out += result */
+    int math;         /* NVQ_MATH_* */
+} nvq_conv_desc;
+/* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
+ *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
+int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
+size_t nvq_sizeof_conv_desc(void);
+
+/* Weight (+ bias) gradient of the same convolution: replaces the parameter half of
+ * aten::convolution_backward.  dw is PyTorch layout [cout][cin_w][k][k]; only the
+ * first cin_w of the `cin` stored input channels receive a gradient.
+ * dw = alpha * sum_pixels x (*) dy  (+ dw if accumulate), same for dbias. */
+typedef struct nvq_wgrad_desc {
+    const float* x;  int x_ld;  int x_coff;  int cin;  int cin_w;
+    const float* dy; int dy_ld; int dy_coff; int cout;
+    float* dw; float* dbias;            /* dbias may be NULL */
+    float* workspace; size_t workspace_bytes;
+    int n, h, w, ksize;
+    float alpha; int accumulate; int math;
+} nvq_wgrad_desc;
+size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */
+int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);
+size_t nvq_sizeof_wgrad_desc(void);
+
+/* ------------------------------------------------------------------ feature extractor
+ * FeatureExtractor.head, super_resolution.py:40-43: relu(conv3x3(frame; W[F,Cin,3,3], b)).
+ * frames: fp32 NCHW clip (B,T,Cin,H,W) contiguous.  Output image index = slot*B + b
+ * holds frame t = t_of_slot[slot]. */
+int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
+                     const int* t_of_slot_host, int nslots,
+                     const float* weight, const float* bias, int F,
+                     float* out, int out_ld, void* stream);
+/* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from dout masked by (act > 0). */
+int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
+                   const int* t_of_slot_host, int nslots,
+                   const float* dout, int dout_ld, const float* act, int act_ld, int F,
+                   float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
+                   int accumulate, void* stream);
+
+/* Depthwise 3x3 (groups = C, no bias), efficient_layers.py:38-46.  weight [C][1][3][3].
+ * flip == 1 gives the input gradient. */
+int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C,
+                       float* out, int out_ld, int N, int H, int W, int flip, void* stream);
+int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C,
+                     int N, int H, int W, float* dweight, float* workspace,
+                     size_t workspace_bytes, int accumulate, void* stream);
+
+/* BatchNorm2d, efficient_layers.py:59,65.  The N images form G = N/group_images groups
+ * (one per feature-extractor call); statistics are per (group, channel) over
+ * group_images*H*W pixels.
+ * nvq_bn_stats: training statistics.  mean/invstd: [G][C] (saved for backward).
+ *   running_* are updated once per group in the order order_host[0..G-1] (the reference
+ *   calls the extractor for t = 0..T-1, super_resolution.py:347-349): momentum 0.1,
+ *   unbiased variance.  running_* may be NULL. */
+int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H, int W,
+                 float eps, float momentum, const int* order_host,
+                 float* mean, float* invstd, float* running_mean, float* running_var,
+                 float* workspace, size_t workspace_bytes, void* stream);
+/* Evaluation: fill mean/invstd [G][C] from the running statistics. */
+int nvq_bn_eval_stats(const float* running_mean, const float* running_var, int C, int G,
+                      float eps, float* mean, float* invstd, void* stream);
+/* y = relu(gamma*(x-mean)*invstd + beta) (+ res).  Images [0, split_images) go to outA,
+ * the rest to outB (image index rebased): lets the centre frame land directly in its
+ * slot of the frame-major aligned stack (super_resolution.py:352,357). */
+int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, int H, int W,
+                      const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, const float* res, int res_ld,
+                      float* outA, int outA_ld, int outA_coff, int split_images,
+                      float* outB, int outB_ld, int outB_coff, void* stream);
+/* Backward of y = relu(bn(x)).  dy is the gradient w.r.t. y; the ReLU mask is recomputed
+ * from x and the statistics (gamma*(x-mean)*invstd + beta > 0), so y itself is not needed.
+ * training != 0: batch-statistics backward; else running-statistics backward.
+ * dgamma/dbeta [C]: summed over all groups, (+)= if accumulate. */
+int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C, int N,
+                         int group_images, int H, int W, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, int training,
+                         float* dx, int dx_ld, float* dgamma, float* dbeta,
+                         float* workspace, size_t workspace_bytes, int accumulate,
+                         void* stream);
+
+/* ------------------------------------------------------------------ motion
+ * LiteFlowNetCorrelation(d=4).forward, efficient_layers.py:313-343.
+ * out[n,p, i*9+j] = (1/C) sum_c x1[n,p,c] * x2[n, p + (i-4, j-4), c]; channels 81..out_ld-1
+ * of each pixel are written as zero.  x2 image index = n % x2_images (centre-frame
+ * features are shared by the T-1 reference frames). */
+int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld,
+                            int x2_images, int C, int N, int H, int W,
+                            float* out, int out_ld, void* stream);
+/* which == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d] * other[n % other_images, p+off(d), c]
+ *             (gradient w.r.t. x1; other = x2)
+ * which == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n, q-off(d), c]
+ *             (gradient w.r.t. x2 contributed by image n; other = x1, other_images = N;
+ *              the caller launches once per reference frame so that the sums into the
+ *              shared centre-frame gradient are ordered) */
+int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
+                             const float* other, int other_ld, int other_images, int C, int N,
+                             int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
+                             void* stream);
+
+/* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
+ * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2]. */
+int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow_ld,
+                     int C, int N, int H, int W, float* out, int out_ld, int out_coff,
+                     void* stream);
+/* dfeat must be pre-initialised (gradients are scattered with float atomics);
+ * dflow [N,H,W,dflow_ld] gets channels 0,1 written and 2..dflow_ld-1 zeroed. */
+int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat,
+                      int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
+                      float* dfeat, int dfeat_ld, float* dflow, int dflow_ld, void* stream);
+
+/* ------------------------------------------------------------------ temporal aggregation
+ * TemporalAggregator.forward softmax + weighted sum, super_resolution.py:174,203-204:
+ * attn = softmax_t(logits[n,p,0..T-1]); weighted[n,p,c] = sum_t aligned[n,p,t*C+c]*attn_t.
+ * Also emits per-block channel sums of `weighted` for the CBAM global average pool:
+ * gap_partial [N][nblk][C] with nblk = nvq_tsum_blocks(H,W). */
+int nvq_tsum_blocks(int H, int W);
+int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, int logits_ld,
+                     int T, int C, int N, int H, int W, float* attn, int attn_ld,
+                     float* weighted, int weighted_ld, float* gap_partial, void* stream);
+/* dw = dweighted + dgap_pix[n][c] (dgap_pix may be NULL);
+ * daligned[n,p,t*C+c] = dw*attn_t ; dlogits = softmax backward of sum_c dw*aligned_t. */
+int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix,
+                      const float* aligned, int aligned_ld, const float* attn, int attn_ld,
+                      int T, int C, int N, int H, int W, float* daligned, int daligned_ld,
+                      float* dlogits, int dlogits_ld, void* stream);
+
+/* CBAM, efficient_layers.py:154-228.
+ * cbam_channel: gap = mean(weighted); hid = relu(W1 gap); ca = sigmoid(W2 hid).
+ *   w1 [R][C], w2 [C][R]; outputs gap [N][C], hid [N][R], ca [N][C]. */
+int nvq_cbam_channel(const float* gap_partial, int nblk, int C, int R, int N, int HW,
+                     const float* w1, const float* w2, float* gap, float* hid, float* ca,
+                     void* stream);
+/* sm[n,p,0] = mean_c(x*ca), sm[n,p,1] = max_c(x*ca); amax = argmax channel. sm ld = 2. */
+int nvq_cbam_pool(const float* x, int x_ld, const float* ca, int C, int N, int H, int W,
+                  float* sm, int* amax, void* stream);
+/* sa = sigmoid(conv7x7(sm; w[1][2][7][7], pad 3)); out = x*ca*sa written at (out,ld,coff). */
+int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const float* sm,
+                           const float* w7, int C, int N, int H, int W, float* sa,
+                           float* out, int out_ld, int out_coff, void* stream);
+/* Backward through out = x*ca*sa:
+ * step1: dpre[n,p] = (sum_c dout*x*ca) * sa*(1-sa)                                   */
+int nvq_cbam_bwd_spatial_pre(const float* dout, int dout_ld, int dout_coff, const float* x,
+                             int x_ld, const float* ca, const float* sa, int C, int N,
+                             int H, int W, float* dpre, void* stream);
+/* step2: dsm = conv7x7^T(dpre) [N,H,W,2]; dw7[1][2][7][7] (+)= sum sm (*) dpre */
+int nvq_cbam_bwd_spatial_conv(const float* dpre, const float* sm, const float* w7, int N,
+                              int H, int W, float* dsm, float* dw7, float* workspace,
+                              size_t workspace_bytes, int accumulate, void* stream);
+/* step3: dxc = dout*sa + dsm0/C + [c==amax] dsm1 ; dx = dxc*ca ;
+ *        dca_partial[n][blk][c] = block sums of dxc*x   (nblk = nvq_tsum_blocks) */
+int nvq_cbam_bwd_scale(const float* dout, int dout_ld, int dout_coff, const float* x, int x_ld,
+                       const float* ca, const float* sa, const float* dsm, const int* amax,
+                       int C, int N, int H, int W, float* dx, int dx_ld, float* dca_partial,
+                       void* stream);
+/* step4: through sigmoid / FC / relu / FC / mean: dw1, dw2 (+)=; dgap_pix[n][c] = dgap/HW */
+int nvq_cbam_bwd_channel(const float* dca_partial, int nblk, int C, int R, int N, int HW,
+                         const float* w1, const float* w2, const float* gap, const float* hid,
+                         const float* ca, float* dw1, float* dw2, float* dgap_pix,
+                         int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ upsampler tail
+ * PixelShuffle(s) + bicubic skip + clamp, efficient_layers.py:101-106 and
+ * super_resolution.py:378-382: out[b,c,h*s+i,w*s+j] =
+ *   clamp(u[b,h,w,c*s*s+i*s+j] + bicubic(frames[b,t_center])[b,c,h*s+i,w*s+j], 0, 1).
+ * out: fp32 NCHW (B,Cimg,H*s,W*s); pass: uint8 1 where 0 <= pre-clamp <= 1. */
+int nvq_shuffle_bicubic_clamp(const float* u, int u_ld, const float* frames, int B, int T,
+                              int t_center, int Cimg, int H, int W, int s, float* out,
+                              uint8_t* pass, void* stream);
+/* du[b,h,w,c*s*s+i*s+j] = dout[b,c,h*s+i,w*s+j] * pass ; channels up to u_ld zero-filled */
+int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H,
+                               int W, int s, float* du, int du_ld, void* stream);
+
+/* ------------------------------------------------------------------ small helpers */
+/* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C */
+int nvq_axpy_slice(float* dst, int dst_ld, int dst_coff, const float* src, int src_ld,
+                   int src_coff, const float* mask, int mask_ld, int mask_coff, int C,
+                   long npix, float alpha, int accumulate, void* stream);
+/* out[c] (+)= alpha * sum_pixels x[p, coff + c] */
+int nvq_colsum(const float* x, int x_ld, int x_coff, int C, long npix, float alpha,
+               float* out, float* workspace, size_t workspace_bytes, int accumulate,
+               void* stream);
+
+/* ------------------------------------------------------------------ EWC (flat buckets)
+ * EWC.penalty, ewc.py:195-232: penalty = lambda/2 * sum F*(theta-theta_star)^2 over a flat
+ * bucket of n floats; result written to *out (device scalar). */
+int nvq_ewc_penalty(const float* theta, const float* theta_star, const float* fisher,
+                    long n, float lambda, float* out, float* workspace,
+                    size_t workspace_bytes, void* stream);
+/* grad (+)= (*scale_dev) * lambda * F * (theta - theta_star): gradient of the penalty
+ * times the upstream scalar gradient (device pointer, may be NULL for 1). */
+int nvq_ewc_penalty_grad(const float* theta, const float* theta_star, const float* fisher,
+                         long n, float lambda, const float* scale_dev, float* grad,
+                         int accumulate, void* stream);
+/* EWC.compute_fisher accumulation, ewc.py:139-141: fisher += grad^2 */
+int nvq_fisher_accumulate(const float* grad, long n, float* fisher, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVQ_H */

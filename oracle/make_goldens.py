@@ -214,6 +214,23 @@ def run_ewc(RefSR, RefEWC):
     print("ewc penalties", blob["penalty0"], blob["penalty1"])
 
 
+def run_default_init(RefSR):
+    """Default (PyTorch) initialisation of the reference module under torch.manual_seed(0):
+    per-tensor [sum, l2, first 4 values] so the drop-in's construction order can be checked."""
+    blob = {}
+    for tag, kw in (("cfg1", dict(scale_factor=2, num_features=32, num_residual_blocks=4, temporal_window=1)),
+                    ("cfg2", dict(scale_factor=2, num_features=64, num_residual_blocks=8, temporal_window=1))):
+        torch.manual_seed(0)
+        ref = RefSR(**kw)
+        for n, t in ref.state_dict().items():
+            f = t.detach().double().reshape(-1)
+            head = np.zeros(4)
+            head[:min(4, f.numel())] = f[:4].numpy()
+            blob[f"{tag}/{n}"] = np.concatenate([[f.sum().item(), f.norm().item()], head])
+    np.savez_compressed(os.path.join(OUT, "default_init_seed0.npz"), **blob)
+    print("default init:", len(blob), "tensors")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -223,6 +240,7 @@ def main():
         run_case(name, cfg, RefSR)
     run_trajectory(RefSR)
     run_ewc(RefSR, RefEWC)
+    run_default_init(RefSR)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {OUT}: {total/1024:.0f} KiB")
 
