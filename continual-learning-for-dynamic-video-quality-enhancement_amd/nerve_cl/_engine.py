@@ -27,6 +27,14 @@ BN_MOM = 0.1
 
 _ws_cache: Dict[torch.device, torch.Tensor] = {}
 
+# When set to a dict, backward() stores intermediate gradients in it (tests / debugging only).
+DEBUG_CAPTURE: Optional[dict] = None
+
+
+def _capture(name: str, t) -> None:
+    if DEBUG_CAPTURE is not None:
+        DEBUG_CAPTURE[name] = t.clone() if torch.is_tensor(t) else t
+
 
 def workspace(device) -> torch.Tensor:
     ws = _ws_cache.get(device)
@@ -211,6 +219,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dres = _new(dev, B, H, W, F)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F), None, Sl(dres), 3, math=math)
     dprev = Sl(dres)
+    _capture("dfused", dfeat_c)
+    _capture("dres", dres)
 
     # ---- residual dense blocks, last to first
     dcats = [_new(dev, B, H, W, g.CAT), _new(dev, B, H, W, g.CAT)] if nb else []
@@ -231,6 +241,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                            mask_c0=cin - GROWTH, mask_c1=cin, math=math)
         dprev = Sl(dcat, F, 0)
 
+    _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F])
     # ---- CBAM
     w1 = P["temporal_aggregator.refine.channel_attention.fc.0.weight"]
     w2 = P["temporal_aggregator.refine.channel_attention.fc.2.weight"]
@@ -264,6 +275,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F), None, Sl(daligned), 3,
                    accumulate=True, math=math)
     K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
+    _capture("dweighted", dweighted)
+    _capture("dlogits", dlogits)
+    _capture("daligned", daligned)
 
     # ---- motion: warp, flow net, correlation
     if NO:
@@ -291,6 +305,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, cout_store=K.pad4(chans[li]), math=math)
             dy_t, dy_c = dx_t, chans[li]
         dcorr = dy_t
+        _capture("f1", acts[1])
+        _capture("dflow", dflow)
+        _capture("dcorr", dcorr)
         center = Sl(sv.aligned, F, c * F)
         K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True)
         for j in range(1, T):
@@ -298,6 +315,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             K.correlation_backward(2, dcorr[lo:hi], Sl(sv.feat_oth).images(lo, hi), Sl(dfeat_c), True)
 
     # ---- feature extractor (all frames batched)
+    _capture("dfeat_all", dfeat_all)
     dcur = dfeat_all
     for k in (2, 1, 0):
         pre = f"feature_extractor.body.{k}."

@@ -80,7 +80,7 @@ class _SRFunction(torch.autograd.Function):
     def forward(ctx, net: "SuperResolutionNet", frames: torch.Tensor, want_inter: bool, *params):
         P = net._tensor_dict()
         out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[3:])
         ctx.net = net
         ctx.sv = sv if need_grad else None
         net._last_intermediates = _engine.intermediates(sv) if want_inter else None
