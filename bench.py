@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the SR hot path: training frames/s at BASELINE cfg2 (scale=2, feat=64, blocks=8,
+T=3, 540p -> 1080p), one process per GPU, weak scaling.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> forward -> MSE -> backward (-> RCCL all-reduce of the flat gradient
+bucket) -> AdamW step, on synthetic U[0,1) clips with T distinct frames, resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line (contract in the round prompt).  `roofline` is the
+dominant kernel's algorithmic FLOP rate measured with HIP events around each of its launches in
+the timed region; `cpu_baseline` is the CPU oracle (a PyTorch-CPU restatement of the reference)
+timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "continual-learning-for-dynamic-video-quality-enhancement_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(args, cfg):
+    """Time the oracle's training step on the host cores on a BOUNDED sample: one clip at 1/16 of
+    the pixels (135x240) and scale the rate by the pixel ratio.  The CPU path is super-linear in
+    pixels (1.05 s at 135x240, 16.5 s at 270x480, ~75 GB of autograd state at
+    540p), so this extrapolation flatters the CPU; it is a reported baseline, not the target."""
+    from oracle import sr_oracle
+    from nerve_cl.models import SuperResolutionNet
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    Hc, Wc = cfg["H"] // 4, cfg["W"] // 4
+    torch.manual_seed(0)
+    ora = sr_oracle.OracleSR(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"])
+    ora.load_named(SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).state_dict())
+    ora.train()
+    opt = torch.optim.AdamW(ora.parameters(), lr=1e-4, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(1, cfg["T"], 3, Hc, Wc, generator=g)
+    y = torch.rand(1, 3, Hc * cfg["scale"], Wc * cfg["scale"], generator=g)
+    times = []
+    budget_t0 = time.perf_counter()
+    for i in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = F.mse_loss(ora(x), y)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu baseline step {i}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
+        if i >= 1 and time.perf_counter() - budget_t0 > 45.0:
+            break
+    timed = sorted(times[1:])
+    t = timed[len(timed) // 2]
+    ratio = (cfg["H"] * cfg["W"]) / (Hc * Wc)
+    return {
+        "value": (1.0 / t) / ratio,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"median of {len(timed)} timed train step(s) (fwd+MSE+bwd+AdamW, fp32, {cores} threads) of the "
+                  f"same net on one {Hc}x{Wc} clip = 1/{ratio:.0f} of the 540p pixels: {t:.2f} s/step; rate divided "
+                  f"by {ratio:.0f} (flatters the CPU, whose cost grows faster than the pixel count); 1 warm-up "
+                  f"step excluded",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=2, help="clips per GPU")
+    ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--blocks", type=int, default=8)
+    ap.add_argument("--window", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from nerve_cl import _nvq, parallel
+    from nerve_cl.models import SuperResolutionNet
+
+    rank, world, local = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = dict(F=args.features, blocks=args.blocks, window=args.window, T=2 * args.window + 1,
+               scale=args.scale, H=args.height, W=args.width)
+
+    torch.manual_seed(0)
+    net = SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).to(dev).train()
+    if world > 1:
+        parallel.enable_data_parallel(net)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-5)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.rand(B, cfg["T"], 3, cfg["H"], cfg["W"], device=dev, generator=g)
+    y = torch.rand(B, 3, cfg["H"] * cfg["scale"], cfg["W"] * cfg["scale"], device=dev, generator=g)
+
+    def step():
+        opt.zero_grad()
+        loss = F.mse_loss(net(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = _nvq.KernelTimer()
+        _nvq.TIMER = timer
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    _nvq.TIMER = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = loss.item()
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    roofline = None
+    kernels = {}
+    if timer is not None:
+        kernels = timer.summary()
+        if kernels:
+            name, d = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])
+            achieved = d["flops"] / (d["ms_total"] * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": name, "launches": d["launches"],
+                "avg_launch_ms": d["ms_total"] / d["launches"],
+                "share_of_step": d["ms_total"] / (ms_per_step * args.steps),
+                "algorithmic_gbs": d["bytes"] / (d["ms_total"] * 1e-3) / 1e9,
+            }
+    line = {
+        "metric": "train frames/sec (2x SR, T=3, 540p->1080p)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg2: SuperResolutionNet(scale={cfg['scale']}, feat={cfg['F']}, "
+                               f"blocks={cfg['blocks']}, T={cfg['T']}) train step on {cfg['H']}x{cfg['W']} -> "
+                               f"{cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss},
+        "roofline": roofline,
+    }
+    if kernels:
+        line["kernel_ms_per_step"] = {k: round(v["ms_total"] / args.steps, 3) for k, v in
+                                      sorted(kernels.items(), key=lambda kv: -kv[1]["ms_total"])}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, cfg)
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

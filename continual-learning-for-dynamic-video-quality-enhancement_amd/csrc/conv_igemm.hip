@@ -289,23 +289,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
             part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
 }
 
+// threads walk the partial layout (coalesced reads); the PyTorch-layout write is scattered once
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
                                     int taps, int cout, int cin_w, float alpha, int accumulate,
                                     float* __restrict__ dw) {
-    const long total = (long)cout * cin_w * taps;
+    const long total = (long)nci * nco * taps * WG_C * WG_C;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
-        const int tap = idx % taps;
-        const int ci = (idx / taps) % cin_w;
-        const int co = (int)(idx / ((long)taps * cin_w));
-        const int cic = ci / WG_C, cil = ci % WG_C, coc = co / WG_C, col = co % WG_C;
-        const size_t stride = (size_t)nci * nco * taps * WG_C * WG_C;
-        const float* p = part + ((size_t)cic * nco + coc) * (taps * WG_C * WG_C) +
-                         (tap * WG_C + cil) * WG_C + col;
+        long t = idx;
+        const int col = t % WG_C; t /= WG_C;
+        const int cil = t % WG_C; t /= WG_C;
+        const int tap = t % taps; t /= taps;
+        const int coc = t % nco;
+        const int cic = (int)(t / nco);
+        const int ci = cic * WG_C + cil, co = coc * WG_C + col;
+        if (ci >= cin_w || co >= cout) continue;
         double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) s += (double)p[k * stride];
+        for (int k = 0; k < nsplit; ++k) s += (double)part[(size_t)k * total + idx];
         const float v = alpha * (float)s;
-        dw[idx] = accumulate ? dw[idx] + v : v;
+        const long o = ((long)co * cin_w + ci) * taps + tap;
+        dw[o] = accumulate ? dw[o] + v : v;
     }
 }
 
@@ -330,19 +333,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nblk, int K,
-                                       float alpha, float* __restrict__ out, int accumulate) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes stride over the partial rows, xor-shuffle tree in double
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int K,
+                                                              float alpha, float* __restrict__ out, int accumulate) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (k >= K) return;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * K + k];
-    const float v = alpha * (float)s;
-    out[k] = accumulate ? out[k] + v : v;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(long)b * K + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        const float v = alpha * (float)s;
+        out[k] = accumulate ? out[k] + v : v;
+    }
 }
 
 int launch_reduce_partials(const float* part, int nblk, int K, float alpha, float* out,
                            int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(K, 128)), dim3(128), 0, s, part, nblk,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, s, part, nblk,
                        K, alpha, out, accumulate);
     return check_launch("reduce_partials");
 }
@@ -473,9 +481,9 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
         hipLaunchKernelGGL((wgrad_f32_kernel<1>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
-    const long total = (long)d.cout * d.cin_w * taps;
+    const long total = (long)nci * nco * taps * WG_C * WG_C;
     int nblk = ceil_div(total, 256);
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 2048) nblk = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, d.workspace, nsplit, nci, nco,
                        taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw);
     rc = check_launch("conv_wgrad_reduce");

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__
 
 // WHICH == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d]        * other[n % oi, p + off(d), c]
 // WHICH == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n,      q - off(d), c]
+// The displacement rows are a runtime loop (9 weights live in registers at a time): a fully
+// unrolled 81-tap body made the compiler hoist every LDS read and spill ~900 VGPRs.
 template <int WHICH>
 __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__ dcorr, int dcorr_ld,
                                                        const float* __restrict__ other, int other_ld,
@@ -96,27 +98,6 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__
     const int gy = ty * CT_H + py, gx = tx * CT_W + px;
     const bool inside = gy < H && gx < W;
     const size_t pix = (size_t)(n * H + (inside ? gy : 0)) * W + (inside ? gx : 0);
-    float wgt[ND];
-    if (WHICH == 1) {
-#pragma unroll
-        for (int k = 0; k < ND / 4; ++k) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inside) v = ld4(dcorr + pix * dcorr_ld + 4 * k);
-            wgt[4 * k] = v.x; wgt[4 * k + 1] = v.y; wgt[4 * k + 2] = v.z; wgt[4 * k + 3] = v.w;
-        }
-        wgt[80] = inside ? dcorr[pix * dcorr_ld + 80] : 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < CN; ++i)
-#pragma unroll
-            for (int j = 0; j < CN; ++j) {
-                const int qy = gy - (i - CD), qx = gx - (j - CD);
-                float v = 0.f;
-                if (inside && qy >= 0 && qy < H && qx >= 0 && qx < W)
-                    v = dcorr[((size_t)(n * H + qy) * W + qx) * dcorr_ld + i * CN + j];
-                wgt[i * CN + j] = v;
-            }
-    }
     const float inv = 1.f / (float)C;
     for (int ch0 = 0; ch0 < C; ch0 += CCH) {
         __syncthreads();
@@ -125,20 +106,36 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__
         float4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int i = 0; i < CN; ++i) {
+            float wgt[CN];
+            if (WHICH == 1) {
 #pragma unroll
-        for (int i = 0; i < CN; ++i)
+                for (int j = 0; j < CN; ++j) wgt[j] = inside ? dcorr[pix * dcorr_ld + i * CN + j] : 0.f;
+            } else {
+                const int qy = gy - (i - CD);
+#pragma unroll
+                for (int j = 0; j < CN; ++j) {
+                    const int qx = gx - (j - CD);
+                    float v = 0.f;
+                    if (inside && qy >= 0 && qy < H && qx >= 0 && qx < W)
+                        v = dcorr[((size_t)(n * H + qy) * W + qx) * dcorr_ld + i * CN + j];
+                    wgt[j] = v;
+                }
+            }
+            const int hy = WHICH == 1 ? py + i : py + 2 * CD - i;
 #pragma unroll
             for (int j = 0; j < CN; ++j) {
-                const int hy = WHICH == 1 ? py + i : py + 2 * CD - i;
                 const int hx = WHICH == 1 ? px + j : px + 2 * CD - j;
                 const float* p = xs + (hy * CHW + hx) * CLD;
-                const float w = wgt[i * CN + j];
+                const float w = wgt[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = ld4(p + 4 * q);
                     acc[q].x += w * b.x; acc[q].y += w * b.y; acc[q].z += w * b.z; acc[q].w += w * b.w;
                 }
             }
+        }
         if (inside) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -232,32 +232,47 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 struct GroupOrder { int g[NVQ_MAX_T]; };
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
-                                   long group_pix, float eps, float momentum, GroupOrder order,
-                                   float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__device__ __forceinline__ double block_sum_double(double v, double* scratch) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// one 256-thread block per channel; groups are folded into the running statistics in `order`
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
+                                                          long group_pix, float eps, float momentum, GroupOrder order,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.x;
     float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
     for (int gi = 0; gi < G; ++gi) {
         const int g = order.g[gi];
-        double s = 0.0, q = 0.0;
         const float* p = part + (size_t)g * nblk * 2 * C;
-        for (int b = 0; b < nblk; ++b) {
+        double s = 0.0, q = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) {
             s += (double)p[(size_t)b * 2 * C + c];
             q += (double)p[(size_t)b * 2 * C + C + c];
         }
+        s = block_sum_double(s, scratch);
+        q = block_sum_double(q, scratch);
         const double m = s / (double)group_pix;
         double var = q / (double)group_pix - m * m;
         if (var < 0.0) var = 0.0;
-        mean[g * C + c] = (float)m;
-        invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
         const double unb = group_pix > 1 ? var * (double)group_pix / (double)(group_pix - 1) : var;
         rm = (1.f - momentum) * rm + momentum * (float)m;
         rv = (1.f - momentum) * rv + momentum * (float)unb;
+        if (threadIdx.x == 0) {
+            mean[g * C + c] = (float)m;
+            invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
-    if (rmean) rmean[c] = rm;
-    if (rvar) rvar[c] = rv;
+    if (threadIdx.x == 0) {
+        if (rmean) rmean[c] = rm;
+        if (rvar) rvar[c] = rv;
+    }
 }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
@@ -336,26 +351,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 }
 
 // sums[g][2C] (device), dgamma/dbeta
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
-                                       float* __restrict__ sums, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.x;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < G; ++g) {
-        double s1 = 0.0, s2 = 0.0;
         const float* p = part + (size_t)g * nblk * 2 * C;
-        for (int b = 0; b < nblk; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) {
             s1 += (double)p[(size_t)b * 2 * C + c];
             s2 += (double)p[(size_t)b * 2 * C + C + c];
         }
-        sums[(size_t)g * 2 * C + c] = (float)s1;
-        sums[(size_t)g * 2 * C + C + c] = (float)s2;
+        s1 = block_sum_double(s1, scratch);
+        s2 = block_sum_double(s2, scratch);
+        if (threadIdx.x == 0) {
+            sums[(size_t)g * 2 * C + c] = (float)s1;
+            sums[(size_t)g * 2 * C + C + c] = (float)s2;
+        }
         tb += s1;
         tg += s2;
     }
-    dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
-    dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
+    if (threadIdx.x == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)tg : (float)tg;
+        dbeta[c] = accumulate ? dbeta[c] + (float)tb : (float)tb;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
@@ -531,7 +552,7 @@ int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H
     if (rc) return rc;
     GroupOrder order;
     for (int i = 0; i < NVQ_MAX_T; ++i) order.g[i] = i < G ? (order_host ? order_host[i] : i) : 0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, workspace, nblk, C, G, group_pix,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, group_pix,
                        eps, momentum, order, mean, invstd, running_mean, running_var);
     return check_launch("bn_finalize");
 }
@@ -577,7 +598,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
                        invstd, gamma, beta, workspace);
     int rc = check_launch("bn_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, workspace, nblk, C, G, sums,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, sums,
                        dgamma, dbeta, accumulate);
     rc = check_launch("bn_bwd_finalize");
     if (rc) return rc;

@@ -171,6 +171,46 @@ class Sl:
         return ptr(self.t, self.coff)
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the current stream (bench.py only)."""
+
+    def __init__(self):
+        self.records = []          # (label, flops, bytes, ev0, ev1)
+        self.enabled = True
+
+    def start(self):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, ev0, label, flops, nbytes):
+        if ev0 is None:
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.records.append((label, flops, nbytes, ev0, ev1))
+
+    def summary(self):
+        """{label: dict(launches, ms_total, flops, bytes)} (call after a device synchronize)."""
+        out = {}
+        for label, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(label, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms_total"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _nt(cout: int) -> int:
+    return 16 if cout <= 16 else (32 if cout <= 32 else 64)
+
+
 def wgrad_workspace_bytes() -> int:
     return int(lib().nvq_wgrad_workspace_bytes())
 
@@ -195,8 +235,9 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
                  relu: bool = False, alpha: float = 1.0, accumulate: bool = False,
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
-                 mask_c1: int = 0, math: int = MATH_F32) -> None:
+                 mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None) -> None:
     n, h, w, _ = x.t.shape
+    ev0 = TIMER.start() if TIMER is not None else None
     assert out.t.shape[:3] == x.t.shape[:3]
     d = ConvDesc()
     d.inp, d.in_ld, d.in_coff, d.cin = ptr(x.t), x.ld, x.coff, x.c
@@ -213,12 +254,19 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.relu, d.alpha, d.accumulate, d.math = int(relu), alpha, int(accumulate), math
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
+    if ev0 is not None:
+        cin = x.c if alg_cin is None else alg_cin
+        planes = cin + out.c + (res.c if res is not None else 0) + (out.c if accumulate else 0) \
+            + (out2.c if out2 is not None else 0) + ((mask_c1 - mask_c0) if mask is not None else 0)
+        TIMER.stop(ev0, f"conv_f32_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
+                   4.0 * n * h * w * planes)
 
 
 def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torch.Tensor],
                ws: torch.Tensor, ksize: int, *, alpha: float = 1.0, accumulate: bool = False,
                math: int = MATH_F32) -> None:
     n, h, w, _ = x.t.shape
+    ev0 = TIMER.start() if TIMER is not None else None
     d = WgradDesc()
     d.x, d.x_ld, d.x_coff, d.cin, d.cin_w = ptr(x.t), x.ld, x.coff, x.c, cin_w
     d.dy, d.dy_ld, d.dy_coff, d.cout = ptr(dy.t), dy.ld, dy.coff, dy.c
@@ -227,6 +275,9 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
+    if ev0 is not None:
+        TIMER.stop(ev0, f"wgrad_f32_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
+                   4.0 * n * h * w * (cin_w + dy.c))
 
 
 # ----------------------------------------------------------------------------- feature extractor

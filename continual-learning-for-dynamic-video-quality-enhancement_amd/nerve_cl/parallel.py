@@ -1,0 +1,104 @@
+"""Data parallelism for the SR hot path: one process per GPU, RCCL over xGMI.
+
+The reference is single-process (no torch.distributed anywhere); this is
+the one parallel strategy the path needs.  Every rank holds a full replica (8 MB of
+parameters), runs forward/backward on its own shard of the minibatch, and the backward of
+``SuperResolutionNet`` hands its flat gradient bucket (one contiguous fp32 tensor, ~8 MB) to
+ONE all-reduce; the result is divided by the world size (mean of per-rank batch-mean losses =
+loss over the global batch).  The message is small, so the collective is latency-bound and
+sits after the last gradient kernel on the same stream; nothing is bucketed or overlapped
+because there is nothing to overlap with.
+
+``torch.distributed`` with backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU
+tensors (used by the world_size-2 tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> "tuple[int, int, int]":
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (the
+    variables torch.distributed.run exports).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over ranks of one flat bucket (a single collective)."""
+    w = world_size(group)
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(w)
+    return flat
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    if world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def broadcast_state_(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make every replica identical to rank `src` (parameters and buffers)."""
+    if world_size(group) <= 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def flatten(tensors: Iterable[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def unflatten_into_(flat: torch.Tensor, tensors: Iterable[torch.Tensor]) -> None:
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+def enable_data_parallel(module: torch.nn.Module, group=None, broadcast: bool = True) -> torch.nn.Module:
+    """Turn on gradient all-reduce for every SuperResolutionNet inside `module`.
+
+    After this call ``loss.backward()`` leaves rank-averaged gradients in ``.grad`` exactly
+    where a single-process run would leave them, so the reference training loops need no change."""
+    from nerve_cl.models.super_resolution import SuperResolutionNet
+    if broadcast:
+        broadcast_state_(module, 0, group)
+    for m in module.modules():
+        if isinstance(m, SuperResolutionNet):
+            m._grad_bucket_hook = (lambda flat, g=group: allreduce_mean_(flat, g))
+    return module
+
+
+def average_bn_buffers_(module: torch.nn.Module, group=None) -> None:
+    """Average BatchNorm running statistics across ranks (done at checkpoint time; training
+    itself uses per-rank batch statistics, i.e. standard DDP semantics)."""
+    w = world_size(group)
+    if w <= 1:
+        return
+    for n, b in module.named_buffers():
+        if b.dtype.is_floating_point:
+            dist.all_reduce(b, group=group)
+            b.div_(w)
