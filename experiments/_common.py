@@ -1,0 +1,34 @@
+"""Shared bits of the experiment scripts: path setup, PSNR, optional one-process-per-GPU launch."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "continual-learning-for-dynamic-video-quality-enhancement_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+import torch  # noqa: E402
+
+
+def compute_psnr(pred: torch.Tensor, target: torch.Tensor) -> float:
+    """20*log10(1/sqrt(mse)) over the whole batch (reference experiments/train_baseline.py:27-32)."""
+    mse = torch.mean((pred - target) ** 2)
+    if mse == 0:
+        return float("inf")
+    return 20 * torch.log10(1.0 / torch.sqrt(mse)).item()
+
+
+def pick_device():
+    """'cuda' when a HIP device is visible (reference train_baseline.py:37); the SR path has no CPU mode."""
+    from nerve_cl import parallel
+    rank, world, local = parallel.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("no HIP device visible: nerve_cl's super-resolution path runs only on the GPU")
+    torch.cuda.set_device(local)
+    return torch.device("cuda", local), rank, world
+
+
+def shard(n: int, rank: int, world: int) -> slice:
+    """Contiguous shard of a dataset of n samples for this rank."""
+    per = (n + world - 1) // world
+    return slice(rank * per, min(n, (rank + 1) * per))

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Continual-learning task sequence (BASELINE configs[4]): same CLI and loops as the reference's
+experiments/train_continual.py (:15-145) on libnvq.
+
+Declared deviation: the reference script crashes at its first ``ewc.register_task`` because
+``EWC.compute_fisher`` feeds the 4-D loader batch to ``EnhancementEngine.forward`` (which needs 5-D input and
+returns a dict).  Here EWC wraps a thin adapter around the same engine that maps (B,C,H,W) -> (B,3,C,H,W) and
+returns ``['enhanced']``, so the Fisher / penalty actually run; everything up to that point prints what the
+reference prints.  ``--tasks`` / ``--samples`` / ``--epochs`` are additions (defaults = the reference's values)."""
+import argparse
+from pathlib import Path
+
+import _common  # noqa: F401
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader, TensorDataset
+
+from _common import pick_device, shard
+from nerve_cl import parallel
+from nerve_cl.continual import EWC, EpisodicMemory, FOMAML, ContinualDistillation  # noqa: F401
+from nerve_cl.models import EnhancementConfig, EnhancementEngine
+
+OFFSETS = {"sports": 0.2, "animation": -0.2, "movie": 0.0, "news": 0.1}
+
+
+def create_task_data(content_type: str, num_samples: int = 100):
+    off = OFFSETS.get(content_type, 0)
+    return torch.randn(num_samples, 3, 64, 64) + off, torch.randn(num_samples, 3, 128, 128) + off
+
+
+class _ClipAdapter(nn.Module):
+    """4-D frame batch -> engine -> 'enhanced' tensor; shares the engine's parameters."""
+
+    def __init__(self, engine: EnhancementEngine):
+        super().__init__()
+        self.engine = engine
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.engine(x.unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+
+
+def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
+    device = next(model.parameters()).device
+    adapter = _ClipAdapter(model)
+    ewc = EWC(adapter, ewc_lambda=config.get("ewc_lambda", 5000))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    criterion = nn.MSELoss()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    for task_id, (task_name, (lr, hr)) in enumerate(tasks):
+        say(f"\n=== Training on Task {task_id}: {task_name} ===")
+        sl = shard(len(lr), rank, world)
+        loader = DataLoader(TensorDataset(lr[sl], hr[sl]), batch_size=max(16 // world, 1), shuffle=True)
+        for epoch in range(epochs):
+            model.train()
+            total = 0.0
+            for lr_b, hr_b in loader:
+                lr_b, hr_b = lr_b.to(device), hr_b.to(device)
+                optimizer.zero_grad()
+                out = model(lr_b.unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+                loss = criterion(out, hr_b) + ewc.penalty()
+                loss.backward()
+                optimizer.step()
+                total += loss.item()
+            say(f"  Epoch {epoch + 1}: Loss={total / len(loader):.4f}")
+        ewc.register_task(task_id, loader)
+        say(f"  Registered task {task_id} for EWC protection")
+    return model
+
+
+def train_with_replay(model, tasks, memory, config, rank=0, epochs=5):
+    device = next(model.parameters()).device
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    criterion = nn.MSELoss()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    for task_id, (task_name, (lr, hr)) in enumerate(tasks):
+        say(f"\n=== Training on Task {task_id}: {task_name} ===")
+        for epoch in range(epochs):
+            model.train()
+            idx = torch.randperm(len(lr))[:16]
+            lr_b, hr_b = lr[idx].to(device), hr[idx].to(device)
+            if len(memory) > 0:
+                r_lr, r_hr, _ = memory.sample(batch_size=8, device=device)
+                lr_b, hr_b = torch.cat([lr_b, r_lr]), torch.cat([hr_b, r_hr])
+            optimizer.zero_grad()
+            out = model(lr_b.unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+            loss = criterion(out, hr_b)
+            loss.backward()
+            optimizer.step()
+            say(f"  Epoch {epoch + 1}: Loss={loss.item():.4f}")
+        for i in range(min(50, len(lr))):
+            memory.store(lr[i], hr[i], metadata={"content_type": task_name})
+        say(f"  Memory size: {len(memory)}")
+    return model
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--strategy", choices=["ewc", "replay", "maml"], default="ewc")
+    ap.add_argument("--memory-size", type=int, default=200)
+    ap.add_argument("--ewc-lambda", type=float, default=5000)
+    ap.add_argument("--tasks", type=int, default=4)
+    ap.add_argument("--samples", type=int, default=200)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--blocks", type=int, default=8)
+    args = ap.parse_args()
+
+    device, rank, world = pick_device()
+    torch.manual_seed(0)
+    model = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True,
+                                                sr_num_features=args.features,
+                                                sr_num_residual_blocks=args.blocks)).to(device)
+    if world > 1:
+        parallel.enable_data_parallel(model)
+    tasks = [(ct, create_task_data(ct, args.samples)) for ct in list(OFFSETS)[:args.tasks]]
+    config = {"ewc_lambda": args.ewc_lambda}
+    if args.strategy == "ewc":
+        model = train_with_ewc(model, tasks, config, rank, world, args.epochs)
+    elif args.strategy == "replay":
+        memory = EpisodicMemory(capacity=args.memory_size, strategy="stratified")
+        model = train_with_replay(model, tasks, memory, config, rank, args.epochs)
+    # ('maml' has no branch in the reference either: it saves the untrained model)
+    if rank == 0:
+        Path("checkpoints").mkdir(exist_ok=True)
+        torch.save(model.state_dict(), "checkpoints/continual_model.pt")
+        print("\nTraining complete!")
+
+
+if __name__ == "__main__":
+    main()

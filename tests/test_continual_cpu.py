@@ -1,0 +1,46 @@
+"""CPU: host-side continual-learning helpers (replay memory, FOMAML, distillation) stay importable and
+behave as the reference's own tests expect (tests/test_continual.py:14-55,92-123)."""
+import torch
+import torch.nn as nn
+
+from nerve_cl.continual import ContinualDistillation, EpisodicMemory, EWC, FOMAML
+
+
+def test_memory_store_sample_capacity_and_stratification():
+    m = EpisodicMemory(capacity=100)
+    for _ in range(50):
+        m.store(torch.randn(3, 32, 32), torch.randn(3, 64, 64), {"content_type": "test"})
+    assert len(m) == 50
+    lr, hr, meta = m.sample(batch_size=16)
+    assert lr.shape == (16, 3, 32, 32) and hr.shape == (16, 3, 64, 64) and len(meta) == 16
+    m2 = EpisodicMemory(capacity=20)
+    for _ in range(50):
+        m2.store(torch.randn(3, 8, 8), torch.randn(3, 16, 16))
+    assert len(m2) == 20
+    m3 = EpisodicMemory(capacity=30, strategy="stratified", seed=0)
+    for ct in ("sports", "animation", "movie"):
+        for _ in range(20):
+            m3.store(torch.randn(3, 8, 8), torch.randn(3, 16, 16), {"content_type": ct})
+    dist = m3.get_stats()["content_distribution"]
+    assert len(dist) == 3 and max(dist.values()) - min(dist.values()) <= 1 and sum(dist.values()) == 30
+
+
+def test_fomaml_adapt_and_distillation_on_plain_modules():
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(10, 32), nn.ReLU(), nn.Linear(32, 10))
+    maml = FOMAML(model, inner_lr=0.01, inner_steps=5)
+    data = (torch.randn(16, 10), torch.randn(16, 10))
+    adapted = maml.adapt(data, nn.MSELoss())
+    assert adapted is not model and isinstance(adapted, nn.Module)
+    assert nn.MSELoss()(adapted(data[0]), data[1]) < nn.MSELoss()(model(data[0]), data[1])
+    cd = ContinualDistillation(model)
+    losses = cd.compute_loss(data[0], data[1], nn.MSELoss())
+    assert float(losses["distill"]) == 0.0
+    cd.register_task()
+    losses = cd.compute_loss(data[0], data[1], nn.MSELoss())
+    assert set(losses) == {"task", "distill", "total"} and cd.task_count == 1
+
+
+def test_ewc_constructs_on_cpu_but_refuses_to_compute_there():
+    ewc = EWC(nn.Linear(4, 4), ewc_lambda=10)
+    assert ewc.penalty() == 0.0 and ewc.num_tasks == 0 and ewc.mode == "online" and ewc.decay == 0.999
