@@ -1,0 +1,94 @@
+// Shared pieces of the fp32 and bf16 implicit-GEMM convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace nvq {
+
+constexpr int TH = 8;      // tile rows
+constexpr int TW = 32;     // tile cols
+constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
+constexpr int WGRAD_MAX_WG = 512;
+
+static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
+
+// NVQ_MATH_BF16 variants (conv_bf16.hip)
+size_t pack_floats_bf16(int cout, int cin_store, int ksize);
+int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store, int cout_keep,
+              float* wpack, hipStream_t s);
+int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
+int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
+                    hipStream_t s);
+
+// Epilogue of the forward / input-gradient kernels.  acc[cb][pb] is the 16x16 MFMA result with
+// M = output channel, N = pixel: lane (c = lane & 15, g = lane >> 4) holds channels
+// cz*NB*16 + cb*16 + 4g .. +3 of pixel (row = 2*wave + (pb >> 1), x = (pb & 1)*16 + c) of the tile.
+template <int NB>
+__device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&acc)[NB][4], int n, int ty, int tx,
+                                              int cz, int wave, int c, int g, int vec_ok) {
+    constexpr int NT = NB * 16;
+    const int H = d.h, W = d.w;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int row = 2 * wave + (pb >> 1);
+        const int gy = ty * TH + row;
+        const int gx = tx * TW + (pb & 1) * 16 + c;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (size_t)(n * H + gy) * W + gx;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int co = cz * NT + cb * 16 + 4 * g;
+            if (co >= d.cout_store) continue;
+            float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
+            if (vec_ok) {
+                if (d.bias && co < d.cout) {
+                    const float4 b = ld4(d.bias + co);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= d.alpha;
+                if (d.out2) st4(d.out2 + pix * d.out2_ld + d.out2_coff + co, make_float4(v[0], v[1], v[2], v[3]));
+                if (d.res && co < d.res_cmax) {
+                    const float4 r = ld4(d.res + pix * d.res_ld + d.res_coff + co);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                float* op = d.out + pix * d.out_ld + d.out_coff + co;
+                if (d.accumulate) {
+                    const float4 o = ld4(op);
+                    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                }
+                if (d.mask && co >= d.mask_c0 && co < d.mask_c1) {
+                    const float4 m = ld4(d.mask + pix * d.mask_ld + d.mask_coff + co);
+                    if (!(m.x > 0.f)) v[0] = 0.f;
+                    if (!(m.y > 0.f)) v[1] = 0.f;
+                    if (!(m.z > 0.f)) v[2] = 0.f;
+                    if (!(m.w > 0.f)) v[3] = 0.f;
+                }
+                st4(op, make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ce = co + e;
+                    if (ce >= d.cout_store) continue;
+                    float x = v[e];
+                    if (d.bias && ce < d.cout) x += d.bias[ce];
+                    if (d.relu) x = fmaxf(x, 0.f);
+                    x *= d.alpha;
+                    if (d.out2) d.out2[pix * d.out2_ld + d.out2_coff + ce] = x;
+                    if (d.res && ce < d.res_cmax) x += d.res[pix * d.res_ld + d.res_coff + ce];
+                    float* op = d.out + pix * d.out_ld + d.out_coff + ce;
+                    if (d.accumulate) x += *op;
+                    if (d.mask && ce >= d.mask_c0 && ce < d.mask_c1 &&
+                        !(d.mask[pix * d.mask_ld + d.mask_coff + ce] > 0.f))
+                        x = 0.f;
+                    *op = x;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace nvq

@@ -7,18 +7,12 @@
 // One workgroup = 256 threads = 4 waves = an 8 x 32 pixel tile; the halo tile of the current
 // 16-channel K chunk and the matching weight slab are staged in LDS, every wave owns two tile
 // rows (4 pixel blocks of 16) and all NB*16 output channels of the workgroup.
-#include "common.h"
+#include "conv_common.h"
 
 namespace nvq {
 
-constexpr int TH = 8;      // tile rows
-constexpr int TW = 32;     // tile cols
 constexpr int KC = 16;     // input channels per K chunk
 constexpr int XS_LD = 20;  // floats per staged pixel (16 + 4 pad: the 16 pixels of one B-fragment hit 16 distinct 16-B slots)
-constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
-constexpr int WGRAD_MAX_WG = 512;
-
-static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
 // ---------------------------------------------------------------- weight packing
 // wpack[cz][kc][tap][g][n][j]  (g = 0..3 lane group, n = 0..NT-1, j = 0..3) holds
@@ -131,69 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
         }
     }
 
-    // epilogue: lane holds channels co..co+3 (co = cz*NT + cb*16 + 4g) of pixel (row, x0 + c)
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-        const int row = 2 * wave + (pb >> 1);
-        const int gy = ty * TH + row;
-        const int gx = tx * TW + (pb & 1) * 16 + c;
-        if (gy >= H || gx >= W) continue;
-        const size_t pix = (size_t)(n * H + gy) * W + gx;
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            const int co = cz * NT + cb * 16 + 4 * g;
-            if (co >= d.cout_store) continue;
-            float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
-            if (vec_ok) {
-                if (d.bias && co < d.cout) {
-                    const float4 b = ld4(d.bias + co);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (d.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= d.alpha;
-                if (d.out2) st4(d.out2 + pix * d.out2_ld + d.out2_coff + co, make_float4(v[0], v[1], v[2], v[3]));
-                if (d.res && co < d.res_cmax) {
-                    const float4 r = ld4(d.res + pix * d.res_ld + d.res_coff + co);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                }
-                float* op = d.out + pix * d.out_ld + d.out_coff + co;
-                if (d.accumulate) {
-                    const float4 o = ld4(op);
-                    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-                }
-                if (d.mask && co >= d.mask_c0 && co < d.mask_c1) {
-                    const float4 m = ld4(d.mask + pix * d.mask_ld + d.mask_coff + co);
-                    if (!(m.x > 0.f)) v[0] = 0.f;
-                    if (!(m.y > 0.f)) v[1] = 0.f;
-                    if (!(m.z > 0.f)) v[2] = 0.f;
-                    if (!(m.w > 0.f)) v[3] = 0.f;
-                }
-                st4(op, make_float4(v[0], v[1], v[2], v[3]));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ce = co + e;
-                    if (ce >= d.cout_store) continue;
-                    float x = v[e];
-                    if (d.bias && ce < d.cout) x += d.bias[ce];
-                    if (d.relu) x = fmaxf(x, 0.f);
-                    x *= d.alpha;
-                    if (d.out2) d.out2[pix * d.out2_ld + d.out2_coff + ce] = x;
-                    if (d.res && ce < d.res_cmax) x += d.res[pix * d.res_ld + d.res_coff + ce];
-                    float* op = d.out + pix * d.out_ld + d.out_coff + ce;
-                    if (d.accumulate) x += *op;
-                    if (d.mask && ce >= d.mask_c0 && ce < d.mask_c1 &&
-                        !(d.mask[pix * d.mask_ld + d.mask_coff + ce] > 0.f))
-                        x = 0.f;
-                    *op = x;
-                }
-            }
-        }
-    }
+    conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok);
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -380,20 +312,24 @@ using namespace nvq;
 
 extern "C" {
 
-size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize) {
+size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize, int math) {
+    if (math == NVQ_MATH_BF16) return pack_floats_bf16(cout, cin_store, ksize);
     const int NT = choose_nt(cout);
     const size_t ncz = (cout + NT - 1) / NT, nkc = (cin_store + KC - 1) / KC;
     return ncz * nkc * (size_t)(ksize * ksize) * 4 * NT * 4;
 }
 
 int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store,
-                  int cout_keep, float* wpack, void* stream) {
+                  int cout_keep, int math, float* wpack, void* stream) {
     NVQ_REQUIRE(ksize == 1 || ksize == 3, "conv_pack: ksize %d", ksize);
     const int cout = transpose ? cout_keep : cout_w;
     const int cin_real = transpose ? cout_w : cin_w;
     NVQ_REQUIRE(cin_store >= cin_real && cin_store % 4 == 0, "conv_pack: cin_store %d < %d or not %%4",
                 cin_store, cin_real);
     NVQ_REQUIRE(!transpose || cout_keep <= cin_w, "conv_pack: cout_keep %d > cin_w %d", cout_keep, cin_w);
+    NVQ_REQUIRE(math == NVQ_MATH_F32 || math == NVQ_MATH_BF16, "conv_pack: math mode %d", math);
+    if (math == NVQ_MATH_BF16)
+        return pack_bf16(w, cout_w, cin_w, ksize, transpose, cin_store, cout_keep, wpack, (hipStream_t)stream);
     const int NT = choose_nt(cout);
     const int ncz = (cout + NT - 1) / NT, nkc = (cin_store + KC - 1) / KC;
     const long total = (long)ncz * nkc * ksize * ksize * 4 * NT * 4;
@@ -409,7 +345,7 @@ size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }
 
 int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     const nvq_conv_desc d = *dp;
-    NVQ_REQUIRE(d.math == NVQ_MATH_F32, "conv_forward: math mode %d not built", d.math);
+    NVQ_REQUIRE(d.math == NVQ_MATH_F32 || d.math == NVQ_MATH_BF16, "conv_forward: math mode %d", d.math);
     NVQ_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv_forward: ksize %d", d.ksize);
     NVQ_REQUIRE(d.cin > 0 && d.cin % 4 == 0 && d.in_ld % 4 == 0 && d.in_coff % 4 == 0 &&
                     aligned16(d.in),
@@ -435,6 +371,7 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
         vec_ok = 0;
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
     hipStream_t s = (hipStream_t)stream;
+    if (d.math == NVQ_MATH_BF16) return conv_forward_bf16(d, vec_ok, s);
 #define NVQ_LAUNCH_CONV(NB, KS) \
     hipLaunchKernelGGL((conv_f32_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
     if (d.ksize == 3) {
@@ -456,7 +393,7 @@ size_t nvq_wgrad_workspace_bytes(void) {
 
 int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     const nvq_wgrad_desc d = *dp;
-    NVQ_REQUIRE(d.math == NVQ_MATH_F32, "conv_wgrad: math mode %d not built", d.math);
+    NVQ_REQUIRE(d.math == NVQ_MATH_F32 || d.math == NVQ_MATH_BF16, "conv_wgrad: math mode %d", d.math);
     NVQ_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv_wgrad: ksize %d", d.ksize);
     NVQ_REQUIRE(d.cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_coff % 4 == 0 && aligned16(d.x),
                 "conv_wgrad: x must be 16-byte addressable");
@@ -475,11 +412,16 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
                 "conv_wgrad: %d x %d channel chunks exceed the workspace", nci, nco);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(nsplit, nci, nco);
-    if (d.ksize == 3)
-        hipLaunchKernelGGL((wgrad_f32_kernel<3>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
-    else
-        hipLaunchKernelGGL((wgrad_f32_kernel<1>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
-    int rc = check_launch("conv_wgrad");
+    int rc;
+    if (d.math == NVQ_MATH_BF16) {
+        rc = conv_wgrad_bf16(d, nsplit, nci, nco, tilesX, tilesY, ntiles, s);
+    } else {
+        if (d.ksize == 3)
+            hipLaunchKernelGGL((wgrad_f32_kernel<3>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
+        else
+            hipLaunchKernelGGL((wgrad_f32_kernel<1>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
+        rc = check_launch("conv_wgrad");
+    }
     if (rc) return rc;
     const long total = (long)nci * nco * taps * WG_C * WG_C;
     int nblk = ceil_div(total, 256);

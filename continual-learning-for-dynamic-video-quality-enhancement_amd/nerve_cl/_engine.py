@@ -90,7 +90,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         d = _new(dev, NI, H, W, F)
         K.dwconv_forward(cur, P[pre + "depthwise.weight"], d)
         p = _new(dev, NI, H, W, F)
-        wp = K.conv_pack(P[pre + "pointwise.weight"], False, F)
+        wp = K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math)
         K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
         mean, invstd = _new(dev, T, F), _new(dev, T, F)
         if training:
@@ -120,7 +120,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         sv.flow_acts = [corr]
         for li, idx in enumerate((0, 2, 4, 6)):
             w = P[f"motion_estimator.flow_net.{idx}.weight"]
-            wp = K.conv_pack(w, False, x.c)
+            wp = K.conv_pack(w, False, x.c, math=math)
             last = idx == 6
             y = _new(dev, NO, H, W, K.pad4(chans[li + 1]))
             K.conv_forward(x, wp, P[f"motion_estimator.flow_net.{idx}.bias"], Sl(y, chans[li + 1]), 3,
@@ -136,11 +136,11 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     # ---- temporal aggregation
     a1, a2 = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
     logits = _new(dev, B, H, W, g.Tp)
-    K.conv_forward(Sl(aligned), K.conv_pack(P["temporal_aggregator.attention.0.weight"], False, T * F),
+    K.conv_forward(Sl(aligned), K.conv_pack(P["temporal_aggregator.attention.0.weight"], False, T * F, math=math),
                    P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math)
-    K.conv_forward(Sl(a1), K.conv_pack(P["temporal_aggregator.attention.2.weight"], False, F),
+    K.conv_forward(Sl(a1), K.conv_pack(P["temporal_aggregator.attention.2.weight"], False, F, math=math),
                    P["temporal_aggregator.attention.2.bias"], Sl(a2), 3, relu=True, math=math)
-    K.conv_forward(Sl(a2), K.conv_pack(P["temporal_aggregator.attention.4.weight"], False, F),
+    K.conv_forward(Sl(a2), K.conv_pack(P["temporal_aggregator.attention.4.weight"], False, F, math=math),
                    P["temporal_aggregator.attention.4.bias"], Sl(logits, T), 3, cout_store=g.Tp, math=math)
     nblk = K.tsum_blocks(H, W)
     attn, weighted = _new(dev, B, H, W, g.Tp), _new(dev, B, H, W, F)
@@ -168,19 +168,19 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         cat = cats[k]
         for i in range(LAYERS):
             cin = F + GROWTH * i
-            wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin)
+            wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
             K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
                            Sl(cat, GROWTH, cin), 3, relu=True, math=math)
-        wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT)
+        wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
         K.conv_forward(Sl(cat), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
                        res=Sl(cat, F, 0), math=math)
 
     # ---- global fusion + upsampler tail
     fused, gr = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
-    K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F), P["gff.0.bias"], Sl(fused), 3,
+    K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F, math=math), P["gff.0.bias"], Sl(fused), 3,
                    relu=True, out2=Sl(gr), res=center, math=math)
     u = _new(dev, B, H, W, g.Up)
-    K.conv_forward(Sl(fused), K.conv_pack(P["upsampler.conv.weight"], False, F), P["upsampler.conv.bias"],
+    K.conv_forward(Sl(fused), K.conv_pack(P["upsampler.conv.weight"], False, F, math=math), P["upsampler.conv.bias"],
                    Sl(u, g.U), 3, cout_store=g.Up, math=math)
     out = _new(dev, B, g.Cimg, H * scale, W * scale)
     passmask = _new(dev, B, g.Cimg, H * scale, W * scale, dtype=torch.uint8)
@@ -211,13 +211,13 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dfeat_all = _new(dev, NI, H, W, F, zero=True)   # gradient w.r.t. the features of every frame (slot order)
     dfeat_c = dfeat_all[:B]
     dg = _new(dev, B, H, W, F)
-    K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F), None, Sl(dg), 3,
+    K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
                    out2=Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
     # ---- gff
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
     dres = _new(dev, B, H, W, F)
-    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F), None, Sl(dres), 3, math=math)
+    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, Sl(dres), 3, math=math)
     dprev = Sl(dres)
     _capture("dfused", dfeat_c)
     _capture("dres", dres)
@@ -229,14 +229,14 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
         _wgrad(Sl(cat), g.CAT, dprev, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
-        K.conv_forward(dprev, K.conv_pack(P[pre + "lff.weight"], True, F, g.CAT), None, Sl(dcat), 1, alpha=0.2,
+        K.conv_forward(dprev, K.conv_pack(P[pre + "lff.weight"], True, F, g.CAT, math=math), None, Sl(dcat), 1, alpha=0.2,
                        res=dprev, mask=Sl(cat), mask_c0=F + GROWTH * (LAYERS - 1), mask_c1=g.CAT, math=math)
         for i in range(LAYERS - 1, -1, -1):
             cin = F + GROWTH * i
             dy = Sl(dcat, GROWTH, cin)
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
-            K.conv_forward(dy, K.conv_pack(P[pre + f"layers.{i}.0.weight"], True, GROWTH, cin), None,
+            K.conv_forward(dy, K.conv_pack(P[pre + f"layers.{i}.0.weight"], True, GROWTH, cin, math=math), None,
                            Sl(dcat, cin, 0), 3, accumulate=True, mask=Sl(cat) if i > 0 else None,
                            mask_c0=cin - GROWTH, mask_c1=cin, math=math)
         dprev = Sl(dcat, F, 0)
@@ -265,14 +265,14 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     pre = "temporal_aggregator.attention."
     _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", ws, 3, math=math)
     da2 = _new(dev, B, H, W, F)
-    K.conv_forward(Sl(dlogits), K.conv_pack(P[pre + "4.weight"], True, g.Tp, F), None, Sl(da2), 3,
+    K.conv_forward(Sl(dlogits), K.conv_pack(P[pre + "4.weight"], True, g.Tp, F, math=math), None, Sl(da2), 3,
                    mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
     da1 = _new(dev, B, H, W, F)
-    K.conv_forward(Sl(da2), K.conv_pack(P[pre + "2.weight"], True, F, F), None, Sl(da1), 3,
+    K.conv_forward(Sl(da2), K.conv_pack(P[pre + "2.weight"], True, F, F, math=math), None, Sl(da1), 3,
                    mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
-    K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F), None, Sl(daligned), 3,
+    K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F, math=math), None, Sl(daligned), 3,
                    accumulate=True, math=math)
     K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
     _capture("dweighted", dweighted)
@@ -296,7 +296,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             name = f"motion_estimator.flow_net.{idx}."
             _wgrad(Sl(x_t), chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
             cin_store = dy_t.shape[-1]
-            wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li])
+            wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li], math=math)
             dx_t = _new(dev, NO, H, W, x_t.shape[-1])
             if li > 0:
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
@@ -324,7 +324,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                            P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
         _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
         dd = _new(dev, NI, H, W, F)
-        K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F), None, Sl(dd), 1, math=math)
+        K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin = sv.feat0 if k == 0 else sv.acts[k - 1]
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws)
         dx = _new(dev, NI, H, W, F)

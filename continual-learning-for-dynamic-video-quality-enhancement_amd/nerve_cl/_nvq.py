@@ -60,8 +60,8 @@ _IP = C.POINTER(ci)
 SIGNATURES = {
     "nvq_version": (ci, []),
     "nvq_last_error": (C.c_char_p, []),
-    "nvq_conv_pack_floats": (sz, [ci, ci, ci]),
-    "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "nvq_conv_pack_floats": (sz, [ci, ci, ci, ci]),
+    "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
     "nvq_sizeof_conv_desc": (sz, []),
     "nvq_wgrad_workspace_bytes": (sz, []),
@@ -220,14 +220,15 @@ def pad4(c: int) -> int:
 
 
 # ----------------------------------------------------------------------------- convolution
-def conv_pack(w: torch.Tensor, transpose: bool, cin_store: int, cout_keep: Optional[int] = None) -> torch.Tensor:
-    """Pack a PyTorch conv weight [Cout, Cin, k, k] for nvq_conv_forward."""
+def conv_pack(w: torch.Tensor, transpose: bool, cin_store: int, cout_keep: Optional[int] = None,
+              math: int = MATH_F32) -> torch.Tensor:
+    """Pack a PyTorch conv weight [Cout, Cin, k, k] for nvq_conv_forward (mode-specific layout)."""
     cout_w, cin_w, k, _ = w.shape
     keep = (cin_w if cout_keep is None else cout_keep) if transpose else cout_w
-    n = lib().nvq_conv_pack_floats(keep, cin_store, k)
+    n = lib().nvq_conv_pack_floats(keep, cin_store, k, math)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
     check(lib().nvq_conv_pack(ptr(w.contiguous()), cout_w, cin_w, k, int(transpose), cin_store,
-                              keep if transpose else 0, ptr(wp), stream()), "nvq_conv_pack")
+                              keep if transpose else 0, math, ptr(wp), stream()), "nvq_conv_pack")
     return wp
 
 
@@ -258,7 +259,7 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
         cin = x.c if alg_cin is None else alg_cin
         planes = cin + out.c + (res.c if res is not None else 0) + (out.c if accumulate else 0) \
             + (out2.c if out2 is not None else 0) + ((mask_c1 - mask_c0) if mask is not None else 0)
-        TIMER.stop(ev0, f"conv_f32_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
+        TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
                    4.0 * n * h * w * planes)
 
 
@@ -276,7 +277,7 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
-        TIMER.stop(ev0, f"wgrad_f32_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
+        TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
                    4.0 * n * h * w * (cin_w + dy.c))
 
 

@@ -51,8 +51,9 @@ const char* nvq_last_error(void);
  * efficient_layers.py:94-100, pointwise :49-56. */
 
 /* Packed-weight size in floats for a conv with `cout` outputs reading `cin_store`
- * stored input channels (cin_store % 4 == 0). */
-size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize);
+ * stored input channels (cin_store % 4 == 0), for the given NVQ_MATH_* mode (the pack is
+ * mode-specific: fp32 values in 16-channel chunks, or bf16 values in 32-channel chunks). */
+size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize, int math);
 
 /* w: PyTorch layout [cout_w][cin_w][k][k].
  * transpose == 0: forward pack; output channels = cout_w, input channels = cin_w
@@ -61,7 +62,7 @@ size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize);
  *                 `cout_keep` are kept), input channels = cout_w (padded to cin_store),
  *                 taps flipped. */
 int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpose,
-                  int cin_store, int cout_keep, float* wpack, void* stream);
+                  int cin_store, int cout_keep, int math, float* wpack, void* stream);
 
 typedef struct nvq_conv_desc {
     const float* in;  int in_ld;  int in_coff;  int cin;       /* cin % 4 == 0 stored channels */

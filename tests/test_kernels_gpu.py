@@ -424,3 +424,74 @@ def test_ewc_flat_kernels(K):
     acc = fi.cuda().clone()
     K.fisher_accumulate(th.cuda(), acc)
     assert rel(acc, fi + th * th) < 1e-6
+
+
+# ----------------------------------------------------------------------------- NVQ_MATH_BF16 convolutions
+# Reference = fp32 convolution of bf16-ROUNDED operands: bf16 x bf16 products are exact in fp32, so the
+# kernels may differ from it by summation order only (same 2e-5 bound as the fp32 kernels).
+def bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.mark.parametrize("cin,cs,cout,k,N,H,W", CONV_CASES)
+def test_conv_bf16_forward_bias_relu(K, cin, cs, cout, k, N, H, W):
+    x, w, b = rnd(N, cin, H, W), rnd(cout, cin, k, k, scale=0.2), rnd(cout)
+    ref = F.relu(F.conv2d(bf(x), bf(w), b, padding=k // 2))
+    xin = to_nhwc(x, cs)
+    wp = K.conv_pack(w.cuda(), False, cs, math=K.MATH_BF16)
+    cst = K.pad4(cout)
+    out = torch.full((N, H, W, cst + 4), 7.0, device="cuda")
+    K.conv_forward(K.Sl(xin), wp, b.cuda(), K.Sl(out, cout, 0), k, relu=True, cout_store=cst, math=K.MATH_BF16)
+    assert rel(from_nhwc(out, cout), ref) < TOL
+    assert (out[..., cst:] == 7.0).all()
+    # and the rounding itself costs at most ~2^-8 relative against the unrounded fp32 convolution
+    assert rel(from_nhwc(out, cout), F.relu(F.conv2d(x, w, b, padding=k // 2))) < 2e-2
+
+
+def test_conv_bf16_dense_layer_and_lff_epilogues(K):
+    N, H, W, Fc, CAT = 1, 10, 33, 64, 224
+    cat, w, b = rnd(N, CAT, H, W), rnd(Fc, CAT, 1, 1, scale=0.1), rnd(Fc)
+    ref = F.conv2d(bf(cat), bf(w), b) * 0.2 + cat[:, :Fc]
+    catb = to_nhwc(cat)
+    out = torch.zeros(N, H, W, CAT, device="cuda")
+    K.conv_forward(K.Sl(catb), K.conv_pack(w.cuda(), False, CAT, math=K.MATH_BF16), b.cuda(), K.Sl(out, Fc, 32), 1,
+                   alpha=0.2, res=K.Sl(catb, Fc, 0), math=K.MATH_BF16)
+    assert rel(from_nhwc(out, Fc, 32), ref) < TOL
+    x, w3, b3 = rnd(N, 96, H, W), rnd(32, 96, 3, 3, scale=0.1), rnd(32)
+    ref3 = F.relu(F.conv2d(bf(x), bf(w3), b3, padding=1))
+    cat2 = to_nhwc(x, 224)
+    K.conv_forward(K.Sl(cat2, 96, 0), K.conv_pack(w3.cuda(), False, 96, math=K.MATH_BF16), b3.cuda(),
+                   K.Sl(cat2, 32, 96), 3, relu=True, math=K.MATH_BF16)
+    assert rel(from_nhwc(cat2, 32, 96), ref3) < TOL
+
+
+@pytest.mark.parametrize("cin,cout,k", [(96, 32, 3), (224, 64, 1), (81, 128, 3), (64, 2, 3), (64, 12, 3)])
+def test_conv_bf16_input_gradient(K, cin, cout, k):
+    N, H, W = 1, 9, 35
+    x = rnd(N, cin, H, W).requires_grad_()
+    w = rnd(cout, cin, k, k, scale=0.2)
+    dy = rnd(N, cout, H, W, seed=3)
+    F.conv2d(x, bf(w), None, padding=k // 2).backward(bf(dy))
+    old = rnd(N, cin, H, W, seed=9)
+    cs, ld = K.pad4(cout), K.pad4(cin)
+    out = to_nhwc(old, ld)
+    K.conv_forward(K.Sl(to_nhwc(dy, cs)), K.conv_pack(w.cuda(), True, cs, cin, math=K.MATH_BF16), None,
+                   K.Sl(out, cin, 0), k, accumulate=True, cout_store=ld, math=K.MATH_BF16)
+    assert rel(from_nhwc(out, cin), x.grad + old) < TOL
+
+
+@pytest.mark.parametrize("cin,cin_store,cout,k,N,H,W", [
+    (64, 64, 32, 3, 2, 16, 40), (81, 96, 128, 3, 1, 9, 33), (224, 224, 64, 1, 1, 11, 37),
+    (32, 32, 2, 3, 1, 8, 31), (64, 64, 12, 3, 1, 17, 33), (192, 192, 64, 3, 1, 8, 64), (64, 64, 3, 3, 2, 5, 7),
+])
+def test_conv_bf16_weight_gradient(K, cin, cin_store, cout, k, N, H, W):
+    x = rnd(N, cin, H, W)
+    w = rnd(cout, cin, k, k).requires_grad_()
+    dy = rnd(N, cout, H, W, seed=3)
+    F.conv2d(bf(x), w, None, padding=k // 2).backward(bf(dy))
+    dw = torch.zeros(cout, cin, k, k, device="cuda")
+    db = torch.zeros(cout, device="cuda")
+    K.conv_wgrad(K.Sl(to_nhwc(x, cin_store)), cin, K.Sl(to_nhwc(dy, K.pad4(cout)), cout, 0), dw, db, ws_tensor(K), k,
+                 math=K.MATH_BF16)
+    assert rel(dw, w.grad) < TOL
+    assert rel(db, dy.sum((0, 2, 3))) < TOL      # bias gradient is summed in fp32 from the unrounded dy

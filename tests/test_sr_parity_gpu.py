@@ -213,3 +213,33 @@ def test_second_backward_accumulates(SR):
     for n, p in net.named_parameters():
         assert rel(p.grad, 2 * ga[n]) < 1e-5, n
     assert g1.keys() == ga.keys()
+
+
+def test_bf16_math_mode_quality(SR):
+    """NVQ_MATH_BF16 (bf16 MFMA operands, fp32 accumulate/storage) has no counterpart in the reference, so it
+    is judged against the fp32 oracle: PSNR of the output, relative loss difference, and direction of the
+    large gradients (SURVEY.md 7 hard part (v))."""
+    from nerve_cl import _nvq
+    net, ora = build_pair(SR, 32, 4, 1, 2, True)
+    net.math_mode = _nvq.MATH_BF16
+    x = synth.formula_clip(2, 3, 64, 64, seed=3)
+    tgt = synth.formula_target(2, 128, 128, seed=4)
+    out = net(x.cuda())
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    o_out = ora(x)
+    o_loss = F.mse_loss(o_out, tgt)
+    o_loss.backward()
+    psnr = sr_oracle.compute_psnr(out.detach().cpu(), o_out.detach())
+    onamed = ora.named()
+    cos_min, worst = 1.0, None
+    for n, p in net.named_parameters():
+        a, b = p.grad.detach().double().cpu().reshape(-1), onamed[n].grad.double().reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        if "motion_estimator" not in n and cos < cos_min:
+            cos_min, worst = cos, n
+    print(f"  bf16 math: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, "
+          f"min grad cosine (non-flow tensors) {cos_min:.5f} at {worst}")
+    assert psnr > 45.0
+    assert abs(loss.item() - o_loss.item()) < 2e-3 * o_loss.item()
+    assert cos_min > 0.99
