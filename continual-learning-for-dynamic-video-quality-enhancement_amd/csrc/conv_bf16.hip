@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 xr[XPER], yr[YPER];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // fp32 column sums of dy (bias gradient), channels 4*(tid&7)..+3
     auto fetch = [&](int tile) {
         int bt = tile;
         const int tx = bt % tilesX; bt /= tilesX;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
                 }
             }
             yr[k] = v;
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
         }
     };
     auto commit = [&]() {
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
+    wgrad_bias_partial(d, bsum, reinterpret_cast<float*>(lds), nco, cic, coc);
 }
 
 // ---------------------------------------------------------------- host side

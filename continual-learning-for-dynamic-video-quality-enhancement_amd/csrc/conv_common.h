@@ -19,6 +19,24 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s);
 
+// Bias-gradient partials of the wgrad kernels: every thread holds the column sums of the dy pieces it staged
+// (channels 4*(tid&7)..+3 of its co chunk).  The 32 threads that share tid&7 are summed through LDS and the
+// ci-chunk-0 workgroups write bias_part[split][coc][32] behind the weight partial slabs.
+__device__ __forceinline__ void wgrad_bias_partial(const nvq_wgrad_desc& d, float4 bsum, float* lds, int nco, int cic,
+                                                   int coc) {
+    if (cic != 0 || d.dbias == nullptr) return;     // uniform per workgroup
+    __syncthreads();
+    st4(lds + 4 * threadIdx.x, bsum);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int q = threadIdx.x >> 2, e = threadIdx.x & 3;   // channel 4q+e of the chunk
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s += lds[4 * (8 * k + q) + e];
+        float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+        bp[((size_t)blockIdx.x * nco + coc) * WG_C + threadIdx.x] = s;
+    }
+}
+
 // Epilogue of the forward / input-gradient kernels.  acc[cb][pb] is the 16x16 MFMA result with
 // M = output channel, N = pixel: lane (c = lane & 15, g = lane >> 4) holds channels
 // cz*NB*16 + cb*16 + 4g .. +3 of pixel (row = 2*wave + (pb >> 1), x = (pb & 1)*16 + c) of the tile.

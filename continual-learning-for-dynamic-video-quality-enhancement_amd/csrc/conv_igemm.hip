@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
     f32x4 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of dy, channels 4*(tid&7)..+3 (bias gradient)
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int bt = tile;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
                 }
             }
             st4(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4)), v);
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
         }
         __syncthreads();
 
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
+    wgrad_bias_partial(d, bsum, lds, nco, cic, coc);
 }
 
 // threads walk the partial layout (coalesced reads); the PyTorch-layout write is scattered once
@@ -241,6 +244,23 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
         const float v = alpha * (float)s;
         const long o = ((long)co * cin_w + ci) * taps + tap;
         dw[o] = accumulate ? dw[o] + v : v;
+    }
+}
+
+// one wave per output channel: sums bias_part[split][coc][32] over the splits in double
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int nco,
+                                                                int cout, float alpha, int accumulate,
+                                                                float* __restrict__ dbias) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (co >= cout) return;
+    const int coc = co / WG_C, col = co % WG_C;
+    double s = 0.0;
+    for (int k = lane; k < nsplit; k += 64) s += (double)bp[((size_t)k * nco + coc) * WG_C + col];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        const float v = alpha * (float)s;
+        dbias[co] = accumulate ? dbias[co] + v : v;
     }
 }
 
@@ -431,9 +451,11 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     rc = check_launch("conv_wgrad_reduce");
     if (rc) return rc;
     if (d.dbias) {
-        float* ws2 = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
-        rc = colsum_impl(d.dy, d.dy_ld, d.dy_coff, d.cout, (long)d.n * d.h * d.w, d.alpha, d.dbias, ws2,
-                         (size_t)512 * 256 * sizeof(float), d.accumulate, s);
+        // bias_part[split][coc][32] written by the ci-chunk-0 workgroups; channel = coc*32 + lane
+        const float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(ceil_div(d.cout, 4)), dim3(256), 0, s, bp, nsplit, nco,
+                           d.cout, d.alpha, d.accumulate, d.dbias);
+        rc = check_launch("conv_wgrad_bias_reduce");
     }
     return rc;
 }

@@ -213,15 +213,10 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     st4(out + pix * out_ld + out_coff + 4 * c4, acc);
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, float4 v, float w) {
-    atomicAdd(p + 0, v.x * w);
-    atomicAdd(p + 1, v.y * w);
-    atomicAdd(p + 2, v.z * w);
-    atomicAdd(p + 3, v.w * w);
-}
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-// C/4 must be a power of two <= 64 so the lanes of one pixel sit in one wave.
+// One thread per (pixel, channel): the lanes of a pixel issue their float atomics on C consecutive floats
+// (256 contiguous bytes for C = 64), the access shape global float atomics run at full rate for.
+// L = min(C, 64) lanes per pixel (a power of two, so the lanes of one pixel sit in one wave); for C > 64
+// every lane walks channels ch, ch + 64, ...
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                        const float* __restrict__ feat, int feat_ld,
                                                        const float* __restrict__ flow, int flow_ld, int C,
@@ -229,34 +224,36 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ dflow, int dflow_ld, long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
+    const int L = C < 64 ? C : 64;
+    const int ch0 = gid % L;
+    const long pix = gid / L;
     const int x = pix % W;
     const int y = (pix / W) % H;
     const long img = pix - ((long)y * W + x);
     const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
-    const float4 go = ld4(dout + pix * dout_ld + dout_coff + 4 * c4);
     const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
     const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
     float gix = 0.f, giy = 0.f;
-    const float* fb = feat + 4 * c4;
-    float* db = dfeat + 4 * c4;
+    for (int ch = ch0; ch < C; ch += L) {
+    const float go = dout[pix * dout_ld + dout_coff + ch];
+    const float* fb = feat + ch;
+    float* db = dfeat + ch;
     if (g.vnw) { const long o = (img + (long)g.y0 * W + g.x0);
-        atomic_add4(db + o * dfeat_ld, go, g.wnw);
-        const float d = dot4(ld4(fb + o * feat_ld), go); gix -= d * (y_se - g.iy); giy -= d * (x_se - g.ix); }
+        atomicAdd(db + o * dfeat_ld, go * g.wnw);
+        const float d = fb[o * feat_ld] * go; gix -= d * (y_se - g.iy); giy -= d * (x_se - g.ix); }
     if (g.vne) { const long o = (img + (long)g.y0 * W + g.x0 + 1);
-        atomic_add4(db + o * dfeat_ld, go, g.wne);
-        const float d = dot4(ld4(fb + o * feat_ld), go); gix += d * (y_se - g.iy); giy -= d * (g.ix - fx0); }
+        atomicAdd(db + o * dfeat_ld, go * g.wne);
+        const float d = fb[o * feat_ld] * go; gix += d * (y_se - g.iy); giy -= d * (g.ix - fx0); }
     if (g.vsw) { const long o = (img + (long)(g.y0 + 1) * W + g.x0);
-        atomic_add4(db + o * dfeat_ld, go, g.wsw);
-        const float d = dot4(ld4(fb + o * feat_ld), go); gix -= d * (g.iy - fy0); giy += d * (x_se - g.ix); }
+        atomicAdd(db + o * dfeat_ld, go * g.wsw);
+        const float d = fb[o * feat_ld] * go; gix -= d * (g.iy - fy0); giy += d * (x_se - g.ix); }
     if (g.vse) { const long o = (img + (long)(g.y0 + 1) * W + g.x0 + 1);
-        atomic_add4(db + o * dfeat_ld, go, g.wse);
-        const float d = dot4(ld4(fb + o * feat_ld), go); gix += d * (g.iy - fy0); giy += d * (g.ix - fx0); }
-    gix = group_sum(gix, C4);
-    giy = group_sum(giy, C4);
-    if (c4 == 0) {
+        atomicAdd(db + o * dfeat_ld, go * g.wse);
+        const float d = fb[o * feat_ld] * go; gix += d * (g.iy - fy0); giy += d * (g.ix - fx0); }
+    }
+    gix = group_sum(gix, L);
+    giy = group_sum(giy, L);
+    if (ch0 == 0) {
         // grid_sample multiplies by (size-1)/2; the normalisation's autograd divides by (size-1) and doubles
         const float gx = 2.0f * ((gix * ((float)(W - 1) / 2.f)) / (float)(W - 1));
         const float gyv = 2.0f * ((giy * ((float)(H - 1) / 2.f)) / (float)(H - 1));
@@ -318,13 +315,9 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
                       float* dflow, int dflow_ld, void* stream) {
-    const int c4 = C >> 2;
-    NVQ_REQUIRE(C % 4 == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0,
-                "warp_backward: C %d must be a power of two in [4,256]", C);
-    NVQ_REQUIRE(dout_ld % 4 == 0 && dout_coff % 4 == 0 && feat_ld % 4 == 0 && dfeat_ld % 4 == 0 && flow_ld >= 2 &&
-                    dflow_ld >= 2,
-                "warp_backward: alignment");
-    const long total = (long)N * H * W * c4;
+    NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
+    NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
+    const long total = (long)N * H * W * (C < 64 ? C : 64);
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
                        dout_coff, feat, feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, total);
     return check_launch("warp_backward");

@@ -449,7 +449,7 @@ static bool pow2_c4(int C) {
 static int blocks_for(long npix, int C) {
     const int npl = 256 / (C >> 2);
     int nb = ceil_div(npix, (long)npl * 16);
-    if (nb > 512) nb = 512;
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     return nb;
 }
