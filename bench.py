@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="print a per-shape table of the conv launches to stderr")
     args = ap.parse_args()
 
     from nerve_cl import _nvq, parallel
@@ -188,6 +189,13 @@ def main():
             else:                       # bf16 MFMA on fp32-stored activations: HBM-bound
                 roofline = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": gbs / PEAK_HBM_GBS, "algorithmic_tflops": tflops, **common}
+    if timer is not None and args.detail:
+        rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms_total"])
+        print("%-24s %-34s %5s %9s %9s %9s" % ("kernel", "shape", "calls", "ms/step", "TFLOP/s", "alg GB/s"), file=sys.stderr)
+        for (label, shape), d in rows[:40]:
+            sec = d["ms_total"] * 1e-3
+            print("%-24s %-34s %5d %9.3f %9.1f %9.0f" % (label, shape, d["launches"] // args.steps,
+                  d["ms_total"] / args.steps, d["flops"] / sec / 1e12, d["bytes"] / sec / 1e9), file=sys.stderr)
     line = {
         "metric": "train frames/sec (2x SR, T=3, 540p->1080p)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

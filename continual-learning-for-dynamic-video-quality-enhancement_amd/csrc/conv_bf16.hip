@@ -11,10 +11,15 @@ namespace nvq {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece (HIP's uint4 struct defeats SROA)
 
 constexpr int KCB = 32;    // input channels per K chunk
 constexpr int XSB = 48;    // bf16 per staged pixel: 32 data + 16 pad (96 B: the 16 pixels x 4 k-groups of one
                            // ds_read_b128 / ds_read_b64_tr_b16 instruction land on distinct 16-B slots)
+
+// Per-(cz, kc) weight slab in the packed buffer / in LDS, padded so that 256 threads move it as a whole number
+// of 16-byte pieces each (unconditional loads: a partially initialised register array gets spilled).
+__host__ __device__ constexpr int ws_stride_halfs(int taps, int NT) { return ((taps * 4 * NT * 8 + 2047) / 2048) * 2048; }
 
 __device__ __forceinline__ bf16x4 cvt4(float4 v) {
     return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -27,15 +32,18 @@ __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
 // wpack[cz][kc][tap][g][n][j] (g = 0..3, n = 0..NT-1, j = 0..7) = bf16(W[cout = cz*NT + n][ch = kc*32 + 8g + j][tap])
 __global__ void pack_bf16_kernel(const float* __restrict__ w, int cout_w, int cin_w, int taps, int transpose,
                                  int cout_keep, int NT, int ncz, int nkc, __bf16* __restrict__ wp) {
-    const long total = (long)ncz * nkc * taps * 4 * NT * 8;
+    const int stride = ws_stride_halfs(taps, NT);
+    const long total = (long)ncz * nkc * stride;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        long t = idx;
+        long t = idx % stride;
+        const long slab = idx / stride;
+        if (t >= (long)taps * 4 * NT * 8) { wp[idx] = (__bf16)0.f; continue; }
         const int j = t & 7; t >>= 3;
         const int n = t % NT; t /= NT;
         const int g = t & 3; t >>= 2;
-        const int tap = t % taps; t /= taps;
-        const int kc = t % nkc; t /= nkc;
-        const int cz = (int)t;
+        const int tap = (int)t;
+        const int kc = slab % nkc;
+        const int cz = (int)(slab / nkc);
         const int co = cz * NT + n;
         const int ch = kc * KCB + 8 * g + j;
         float v = 0.f;
@@ -58,10 +66,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
     constexpr int HW_ = TW + 2 * HALO;
     constexpr int HH_ = TH + 2 * HALO;
     constexpr int NPIX = HW_ * HH_;
-    constexpr int WS_HALFS = TAPS * 4 * NT * 8;
+    constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);     // padded slab (see ws_stride_halfs)
     constexpr int XITEMS = NPIX * 4;                          // (pixel, 8-channel group) pieces per chunk
     constexpr int XPER = (XITEMS + 255) / 256;
-    constexpr int WPER = (WS_HALFS / 8 + 255) / 256;          // 16-byte pieces per thread
+    constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread (exact)
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;
@@ -88,51 +96,50 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
     const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack) + (size_t)cz * nkc * WS_HALFS;
     const float* in = d.in + d.in_coff;
 
-    // per-thread global offsets of the activation pieces (independent of the chunk)
-    long xoff[XPER];
+    // Per-thread element offsets of the activation pieces (chunk independent).  Out-of-image pieces point at
+    // element 0 and are zeroed by a select, so every load below is unconditional (no branches, no spills).
+    unsigned xoff[XPER];
+    bool xok[XPER];
 #pragma unroll
     for (int k = 0; k < XPER; ++k) {
         const int item = tid + k * 256;
         const int hp = item >> 2;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
-        xoff[k] = (item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                      ? ((long)(n * H + gy) * W + gx) * d.in_ld + 8 * (item & 3)
-                      : -1;
+        xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld + 8 * (item & 3)) : 0u;
     }
+    const int chg = 8 * (tid & 3);                            // channel group of this thread's pieces (256 % 4 == 0)
     float4 xr[XPER][2];
-    uint4 wr[WPER];
+    u32x4 wr[WPER];
 
-    auto fetch = [&](int kc) {
+    bool cv0 = false, cv1 = false;                            // channel validity of the chunk held in xr
+    auto fetch = [&](int kc) {                                // raw loads only: nothing here may USE a loaded value
+        const int ch = kc * KCB + chg;
+        cv0 = ch < d.cin;
+        cv1 = ch + 4 < d.cin;
+        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;   // invalid -> element 0 of the pixel slice
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
-            xr[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xr[k][1] = xr[k][0];
-            const int ch = kc * KCB + 8 * ((tid + k * 256) & 3);
-            if (xoff[k] >= 0) {
-                if (ch < d.cin) xr[k][0] = ld4(in + xoff[k] + kc * KCB);
-                if (ch + 4 < d.cin) xr[k][1] = ld4(in + xoff[k] + kc * KCB + 4);
-            }
+            xr[k][0] = ld4(in + xoff[k] + (xok[k] ? o0 : 0));
+            xr[k][1] = ld4(in + xoff[k] + (xok[k] ? o1 : 0));
         }
-        const uint4* wsrc = reinterpret_cast<const uint4*>(wp_base + (size_t)kc * WS_HALFS);
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
 #pragma unroll
-        for (int k = 0; k < WPER; ++k) {
-            const int i = tid + k * 256;
-            if (i < WS_HALFS / 8) wr[k] = wsrc[i];
-        }
+        for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
     };
     auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
+            const bool v0 = xok[k] && cv0, v1 = xok[k] && cv1;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (item < XITEMS)
-                *reinterpret_cast<bf16x8*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = cvt8(xr[k][0], xr[k][1]);
+                *reinterpret_cast<bf16x8*>(xs + (item >> 2) * XSB + 8 * (item & 3)) =
+                    cvt8(v0 ? xr[k][0] : z, v1 ? xr[k][1] : z);
         }
 #pragma unroll
-        for (int k = 0; k < WPER; ++k) {
-            const int i = tid + k * 256;
-            if (i < WS_HALFS / 8) reinterpret_cast<uint4*>(ws)[i] = wr[k];
-        }
+        for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
     };
 
     fetch(0);
@@ -204,54 +211,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
 
     float4 xr[XPER], yr[YPER];
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // fp32 column sums of dy (bias gradient), channels 4*(tid&7)..+3
+    const int q4 = 4 * (tid & 7);                    // channel offset of this thread's pieces inside the chunk
+    const bool xch_ok = cic * WG_C + q4 < d.cin;
+    const int ych = coc * WG_C + q4;
+    const bool ych_ok = ych < d.cout;
+    // all loads unconditional (invalid pieces read element 0 of the slice); the validity masks are applied in
+    // commit(), so that nothing between the prefetch and the next commit uses a loaded value
+    unsigned xmask = 0, ymask = 0;
     auto fetch = [&](int tile) {
         int bt = tile;
         const int tx = bt % tilesX; bt /= tilesX;
         const int ty = bt % tilesY;
         const int n = bt / tilesY;
+        xmask = 0; ymask = 0;
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
-            const int hp = item >> 3, qq = item & 7;
+            const int hp = item >> 3;
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
-            const int ch = cic * WG_C + 4 * qq;
-            xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && ch < d.cin)
-                xr[k] = ld4(x + ((size_t)(n * H + gy) * W + gx) * d.x_ld + ch);
+            const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch_ok;
+            xmask |= (ok ? 1u : 0u) << k;
+            xr[k] = ld4(x + (ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * WG_C + q4 : 0));
         }
 #pragma unroll
         for (int k = 0; k < YPER; ++k) {
             const int item = tid + k * 256;
-            const int pp = item >> 3, qq = item & 7;
+            const int pp = item >> 3;
             const int py = pp / TW, px = pp - py * TW;
             const int gy = ty * TH + py, gx = tx * TW + px;
-            const int ch = coc * WG_C + 4 * qq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W) {
-                const float* src = dy + ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ch;
-                if (ch + 3 < d.cout) {
-                    v = ld4(src);
-                } else {
-                    if (ch < d.cout) v.x = src[0];
-                    if (ch + 1 < d.cout) v.y = src[1];
-                    if (ch + 2 < d.cout) v.z = src[2];
-                }
-            }
-            yr[k] = v;
-            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            // the dy slice is readable up to a multiple of 4 channels (checked on the host); channels >= cout
+            // only feed partial sums that are never written
+            const bool ok = gy < H && gx < W && ych_ok;
+            ymask |= (ok ? 1u : 0u) << k;
+            yr[k] = ld4(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0));
         }
     };
     auto commit = [&]() {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
-            if (item < XITEMS) *reinterpret_cast<bf16x4*>(xs + (item >> 3) * XSB + 4 * (item & 7)) = cvt4(xr[k]);
+            if (item < XITEMS)
+                *reinterpret_cast<bf16x4*>(xs + (item >> 3) * XSB + 4 * (item & 7)) = cvt4((xmask >> k) & 1 ? xr[k] : z);
         }
 #pragma unroll
         for (int k = 0; k < YPER; ++k) {
             const int item = tid + k * 256;
-            *reinterpret_cast<bf16x4*>(dys + (item >> 3) * XSB + 4 * (item & 7)) = cvt4(yr[k]);
+            const float4 v = (ymask >> k) & 1 ? yr[k] : z;
+            *reinterpret_cast<bf16x4*>(dys + (item >> 3) * XSB + 4 * (item & 7)) = cvt4(v);
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;   // bias column sums, unrounded values
         }
     };
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
 size_t pack_floats_bf16(int cout, int cin_store, int ksize) {
     const int NT = choose_nt(cout);
     const size_t ncz = (cout + NT - 1) / NT, nkc = (cin_store + KCB - 1) / KCB;
-    return ncz * nkc * (size_t)(ksize * ksize) * 4 * NT * 8 / 2;   // bf16 pairs per float
+    return ncz * nkc * (size_t)ws_stride_halfs(ksize * ksize, NT) / 2;   // bf16 pairs per float
 }
 
 int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store, int cout_keep,
@@ -306,7 +315,7 @@ int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, i
     const int cout = transpose ? cout_keep : cout_w;
     const int NT = choose_nt(cout);
     const int ncz = (cout + NT - 1) / NT, nkc = (cin_store + KCB - 1) / KCB;
-    const long total = (long)ncz * nkc * ksize * ksize * 4 * NT * 8;
+    const long total = (long)ncz * nkc * ws_stride_halfs(ksize * ksize, NT);
     int nblk = ceil_div(total, 256);
     if (nblk > 2048) nblk = 2048;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(nblk), dim3(256), 0, s, w, cout_w, cin_w, ksize * ksize, transpose,

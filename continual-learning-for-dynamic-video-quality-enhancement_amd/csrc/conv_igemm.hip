@@ -42,6 +42,42 @@ __global__ void pack_kernel(const float* __restrict__ w, int cout_w, int cin_w, 
     }
 }
 
+// ---------------------------------------------------------------- dense-block backward weights
+// The gradient w.r.t. growth slice y_i of a residual dense block is a sum over every later consumer:
+//   d y_i = mask_i * ( 0.2 * lff^T(gout)[y_i]  +  sum_{j>i} conv_j^T(d y_j)[y_i] )
+// With the gradient buffer laid out [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] this is ONE 3x3 convolution
+// over the channel prefix [0, F + 32(4-i)) (the 1x1 lff term sits on the centre tap) - the mirror image of
+// the forward dense layer, with no read-modify-write accumulation.  This kernel assembles those combined
+// weights in PyTorch layout: targets t = 0..4 -> Wb_{4-t} [32][F+32t][3][3], then Wb_x [F][F+160][3][3].
+struct RdbSrc { const float* lff; const float* w[5]; };
+
+__global__ void rdb_bwd_weights_kernel(RdbSrc src, int F, float* __restrict__ out, long total) {
+    const int CAT = F + 160;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long rem = idx;
+        int i = -1, cinb = 0, cout = 0;          // i = growth layer whose gradient this target produces (-1: x)
+        for (int t = 0; t < 5; ++t) {
+            const long sz = 32L * (F + 32 * t) * 9;
+            if (rem < sz) { i = 4 - t; cinb = F + 32 * t; cout = 32; break; }
+            rem -= sz;
+        }
+        if (i < 0) { cinb = CAT; cout = F; }
+        const int tap = rem % 9;
+        const int c = (rem / 9) % cinb;
+        const int o = (int)(rem / (9L * cinb));
+        (void)cout;
+        const int ych = i >= 0 ? F + 32 * i + o : o;      // channel of the forward concat this output refers to
+        float v = 0.f;
+        if (c < F) {
+            if (tap == 4) v = 0.2f * src.lff[(long)c * CAT + ych];
+        } else {
+            const int j = 4 - (c - F) / 32, m = (c - F) % 32;
+            v = src.w[j][((long)m * (F + 32 * j) + ych) * 9 + (8 - tap)];
+        }
+        out[idx] = v;
+    }
+}
+
 // ---------------------------------------------------------------- forward / dgrad
 template <int NB, int KS>
 __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d, int tilesX,
@@ -360,6 +396,19 @@ int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpos
     return check_launch("conv_pack");
 }
 
+size_t nvq_rdb_backward_weights_floats(int F) { return (size_t)9 * (32 * (5 * F + 320) + (size_t)F * (F + 160)); }
+
+int nvq_rdb_backward_weights(const float* lff, const float* w0, const float* w1, const float* w2, const float* w3,
+                             const float* w4, int F, float* out, void* stream) {
+    NVQ_REQUIRE(F > 0 && F % 4 == 0, "rdb_backward_weights: F %d", F);
+    RdbSrc src{lff, {w0, w1, w2, w3, w4}};
+    const long total = (long)nvq_rdb_backward_weights_floats(F);
+    int nblk = ceil_div(total, 256);
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(rdb_bwd_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, src, F, out, total);
+    return check_launch("rdb_backward_weights");
+}
+
 size_t nvq_sizeof_conv_desc(void) { return sizeof(nvq_conv_desc); }
 size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }
 
@@ -420,6 +469,8 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     NVQ_REQUIRE(d.dy_ld % 4 == 0 && d.dy_coff % 4 == 0 && aligned16(d.dy),
                 "conv_wgrad: dy must be 16-byte addressable");
     NVQ_REQUIRE(d.cin_w > 0 && d.cin_w <= d.cin && d.cout > 0, "conv_wgrad: channels");
+    NVQ_REQUIRE(d.math != NVQ_MATH_BF16 || d.dy_coff + ((d.cout + 3) & ~3) <= d.dy_ld,
+                "conv_wgrad(bf16): the dy slice must be readable up to a multiple of 4 channels");
     NVQ_REQUIRE(d.workspace_bytes >= nvq_wgrad_workspace_bytes(), "conv_wgrad: workspace too small");
     const int taps = d.ksize * d.ksize;
     const int nci = (d.cin_w + WG_C - 1) / WG_C, nco = (d.cout + WG_C - 1) / WG_C;

@@ -216,30 +216,33 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     # ---- gff
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
-    dres = _new(dev, B, H, W, F)
-    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, Sl(dres), 3, math=math)
-    dprev = Sl(dres)
-    _capture("dfused", dfeat_c)
-    _capture("dres", dres)
-
-    # ---- residual dense blocks, last to first
+    # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
     dcats = [_new(dev, B, H, W, g.CAT), _new(dev, B, H, W, g.CAT)] if nb else []
+    dagg = _new(dev, B, H, W, F)
+    gout = Sl(dcats[(nb - 1) & 1], F, 0) if nb else Sl(dagg)
+    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
+    _capture("dfused", dfeat_c)
+    _capture("dres", gout.t[..., :F])
+
+    # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
-        _wgrad(Sl(cat), g.CAT, dprev, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
-        K.conv_forward(dprev, K.conv_pack(P[pre + "lff.weight"], True, F, g.CAT, math=math), None, Sl(dcat), 1, alpha=0.2,
-                       res=dprev, mask=Sl(cat), mask_c0=F + GROWTH * (LAYERS - 1), mask_c1=g.CAT, math=math)
+        gout = Sl(dcat, F, 0)
+        _wgrad(Sl(cat), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
+        wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
         for i in range(LAYERS - 1, -1, -1):
+            cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
+            dy = Sl(dcat, GROWTH, cinb)                      # slot of dy_i
+            K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
+                           mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math)
             cin = F + GROWTH * i
-            dy = Sl(dcat, GROWTH, cin)
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
-            K.conv_forward(dy, K.conv_pack(P[pre + f"layers.{i}.0.weight"], True, GROWTH, cin, math=math), None,
-                           Sl(dcat, cin, 0), 3, accumulate=True, mask=Sl(cat) if i > 0 else None,
-                           mask_c0=cin - GROWTH, mask_c1=cin, math=math)
-        dprev = Sl(dcat, F, 0)
+        nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
+        K.conv_forward(Sl(dcat), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
+    dprev = Sl(dagg)
 
     _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F])
     # ---- CBAM

@@ -63,6 +63,8 @@ SIGNATURES = {
     "nvq_conv_pack_floats": (sz, [ci, ci, ci, ci]),
     "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
+    "nvq_rdb_backward_weights_floats": (sz, [ci]),
+    "nvq_rdb_backward_weights": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "nvq_sizeof_conv_desc": (sz, []),
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
@@ -185,18 +187,30 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def stop(self, ev0, label, flops, nbytes):
+    def stop(self, ev0, label, flops, nbytes, shape=""):
         if ev0 is None:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.records.append((label, flops, nbytes, ev0, ev1))
+        self.records.append((label, flops, nbytes, ev0, ev1, shape))
 
     def summary(self):
         """{label: dict(launches, ms_total, flops, bytes)} (call after a device synchronize)."""
         out = {}
-        for label, fl, nb, e0, e1 in self.records:
+        for label, fl, nb, e0, e1, _ in self.records:
             d = out.setdefault(label, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms_total"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+    def by_shape(self):
+        """{(label, shape): dict(...)} for the per-shape table of bench.py --detail."""
+        out = {}
+        for label, fl, nb, e0, e1, shape in self.records:
+            d = out.setdefault((label, shape), dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms_total"] += e0.elapsed_time(e1)
             d["flops"] += fl
@@ -260,7 +274,23 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
         planes = cin + out.c + (res.c if res is not None else 0) + (out.c if accumulate else 0) \
             + (out2.c if out2 is not None else 0) + ((mask_c1 - mask_c0) if mask is not None else 0)
         TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
-                   4.0 * n * h * w * planes)
+                   4.0 * n * h * w * planes, f"n{n} cin{x.c} cout{out.c}" + (" acc" if accumulate else "")
+                   + (" res" if res is not None else "") + (" mask" if mask is not None else ""))
+
+
+def rdb_backward_weights(lff: torch.Tensor, ws: Sequence[torch.Tensor], F: int):
+    """Combined 'mirror' weights of one dense block: returns ([Wb_4, Wb_3, Wb_2, Wb_1, Wb_0], Wb_x) as views
+    of one buffer, PyTorch layout (see nvq_rdb_backward_weights)."""
+    n = lib().nvq_rdb_backward_weights_floats(F)
+    out = torch.empty(n, dtype=torch.float32, device=lff.device)
+    check(lib().nvq_rdb_backward_weights(ptr(lff), *[ptr(w) for w in ws], F, ptr(out), stream()),
+          "nvq_rdb_backward_weights")
+    views, off = [], 0
+    for t in range(5):
+        k = 32 * (F + 32 * t) * 9
+        views.append(out[off:off + k].view(32, F + 32 * t, 3, 3))
+        off += k
+    return views, out[off:].view(F, F + 160, 3, 3)
 
 
 def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torch.Tensor],
@@ -278,7 +308,7 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
         TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
-                   4.0 * n * h * w * (cin_w + dy.c))
+                   4.0 * n * h * w * (cin_w + dy.c), f"n{n} cin{cin_w} cout{dy.c}")
 
 
 # ----------------------------------------------------------------------------- feature extractor

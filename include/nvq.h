@@ -85,6 +85,17 @@ typedef struct nvq_conv_desc {
 int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
 size_t nvq_sizeof_conv_desc(void);
 
+/* Combined weights for the backward of one ResidualDenseBlock (super_resolution.py:245-253) in "mirror"
+ * form.  With the block's gradient buffer laid out [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0], the gradient
+ * of growth slice y_i is ONE 3x3 convolution over the channel prefix [0, F+32(4-i)) (the 0.2*lff^T term on the
+ * centre tap, the transposed/flipped dense-layer weights elsewhere), and the gradient w.r.t. the block input
+ * is one more over all F+160 channels - no read-modify-write accumulation.
+ * lff: [F][F+160][1][1]; w_i: [32][F+32i][3][3].  out holds, in PyTorch layout and in this order,
+ * Wb_4 [32][F], Wb_3 [32][F+32], ..., Wb_0 [32][F+128], Wb_x [F][F+160]  (each [..][3][3]). */
+size_t nvq_rdb_backward_weights_floats(int F);
+int nvq_rdb_backward_weights(const float* lff, const float* w0, const float* w1, const float* w2,
+                             const float* w3, const float* w4, int F, float* out, void* stream);
+
 /* Weight (+ bias) gradient of the same convolution: replaces the parameter half of
  * aten::convolution_backward.  dw is PyTorch layout [cout][cin_w][k][k]; only the
  * first cin_w of the `cin` stored input channels receive a gradient.

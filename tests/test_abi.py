@@ -70,7 +70,7 @@ def test_library_loads_and_exports_everything():
     assert lib.nvq_version() >= 100
     assert lib.nvq_wgrad_workspace_bytes() > 0
     assert lib.nvq_conv_pack_floats(32, 64, 3, 0) == 1 * 4 * 9 * 4 * 32 * 4
-    assert lib.nvq_conv_pack_floats(32, 64, 3, 1) == 1 * 2 * 9 * 4 * 32 * 8 // 2
+    assert lib.nvq_conv_pack_floats(32, 64, 3, 1) == 1 * 2 * 10240 // 2   # bf16 slabs are padded to 2048 halfs
     assert lib.nvq_tsum_blocks(540, 960) >= 1
 
 
