@@ -275,8 +275,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
         const int cic = (int)(t / nco);
         const int ci = cic * WG_C + cil, co = coc * WG_C + col;
         if (ci >= cin_w || co >= cout) continue;
-        double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) s += (double)part[(size_t)k * total + idx];
+        // 8 independent chains: the split loop is a chain of dependent HBM/L2 loads otherwise
+        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += (double)part[(size_t)(k + u) * total + idx];
+        }
+        for (; k < nsplit; ++k) s8[0] += (double)part[(size_t)k * total + idx];
+        const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         const float v = alpha * (float)s;
         const long o = ((long)co * cin_w + ci) * taps + tap;
         dw[o] = accumulate ? dw[o] + v : v;
