@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--scale", type=int, default=2)
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16",
                     help="MFMA operand precision of the convolutions (accumulation and storage are fp32)")
+    ap.add_argument("--fp32-acts", action="store_true",
+                    help="with --math bf16: keep the conv-internal tensors in fp32 (default: bf16 storage)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -127,6 +129,7 @@ def main():
     torch.manual_seed(0)
     net = SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).to(dev).train()
     net.math_mode = _nvq.MATH_BF16 if args.math == "bf16" else _nvq.MATH_F32
+    net.bf16_activations = args.math == "bf16" and not args.fp32_acts
     if world > 1:
         parallel.enable_data_parallel(net)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-5)
@@ -205,7 +208,8 @@ def main():
                                f"blocks={cfg['blocks']}, T={cfg['T']}) train step on {cfg['H']}x{cfg['W']} -> "
                                f"{cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss},
+                   "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss,
+                   "conv_internal_storage": "bf16" if net.bf16_activations else "f32"},
         "roofline": roofline,
     }
     if kernels:

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void cbam_sa_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, int x_ld,
                                                          const float* __restrict__ ca, const float* __restrict__ sa,
                                                          int C, long HW, float* __restrict__ out, int out_ld,
-                                                         int out_coff, long total) {
+                                                         int out_coff, int out_bf16, long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -228,8 +228,14 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
     const float4 v = ld4(x + pix * x_ld + 4 * c4);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float s = sa[pix];
-    st4(out + pix * out_ld + out_coff + 4 * c4,
-        make_float4(v.x * a.x * s, v.y * a.y * s, v.z * a.z * s, v.w * a.w * s));
+    const float4 o = make_float4(v.x * a.x * s, v.y * a.y * s, v.z * a.z * s, v.w * a.w * s);
+    if (out_bf16) {
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(out) + pix * out_ld + out_coff + 4 * c4) =
+            (bf16x4_t){(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+    } else {
+        st4(out + pix * out_ld + out_coff + 4 * c4, o);
+    }
 }
 
 // ---------------------------------------------------------------- CBAM backward
@@ -454,7 +460,8 @@ int nvq_cbam_pool(const float* x, int x_ld, const float* ca, int C, int N, int H
 }
 
 int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const float* sm, const float* w7, int C,
-                           int N, int H, int W, float* sa, float* out, int out_ld, int out_coff, void* stream) {
+                           int N, int H, int W, float* sa, float* out, int out_ld, int out_coff, int out_bf16,
+                           void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0, "cbam_spatial_apply: alignment");
     const int tilesX = (W + SP_T - 1) / SP_T, tilesY = (H + SP_T - 1) / SP_T;
     hipStream_t s = (hipStream_t)stream;
@@ -463,7 +470,7 @@ int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const floa
     if (rc) return rc;
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, x, x_ld, ca, sa, C, (long)H * W,
-                       out, out_ld, out_coff, total);
+                       out, out_ld, out_coff, out_bf16, total);
     return check_launch("cbam_apply");
 }
 

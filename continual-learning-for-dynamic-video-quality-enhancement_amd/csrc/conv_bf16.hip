@@ -1,32 +1,41 @@
-// NVQ_MATH_BF16 convolution kernels: fp32 activations in HBM, operands rounded to bf16 while they
-// are staged into LDS, v_mfma_f32_16x16x32_bf16 with fp32 accumulation, fp32 epilogue.
+// NVQ_MATH_BF16 convolution kernels: operands are bf16 in LDS (activations stored as fp32 are rounded while
+// they are staged, activations stored as bf16 are copied), v_mfma_f32_16x16x32_bf16 with fp32 accumulation,
+// fp32 epilogue arithmetic, output stored as fp32 or bf16 per tensor (nvq_conv_desc::*_bf16).
 //
-// At 16x the fp32 MFMA rate these kernels are HBM-bound (a 32-channel chunk of an 8x32 tile is 43.5 KB of
-// fp32 reads for ~1.2-2.3k MFMA cycles), so the structure is built around keeping loads in flight:
-// the next chunk / tile is fetched into registers while the current one is consumed from LDS.
+// At 16x the fp32 MFMA rate these kernels are HBM-bound, so the structure is built around keeping loads in
+// flight: the next K chunk / pixel tile is fetched into registers while the current one is consumed from LDS.
+// Rules the prefetch obeys (each one was a measured stall):
+//   * every prefetch load is unconditional (invalid pieces read element 0 and are masked at commit time):
+//     branches around loads serialise them;
+//   * nothing between the prefetch and the next commit may USE a loaded value (not even a select);
+//   * register pieces are ext_vector types: HIP's uint4 struct is not scalar-replaced and lands in scratch;
+//   * the packed weight slab is padded to a whole number of 16-byte pieces per thread.
 #include "conv_common.h"
 
 namespace nvq {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece (HIP's uint4 struct defeats SROA)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece
 
 constexpr int KCB = 32;    // input channels per K chunk
 constexpr int XSB = 48;    // bf16 per staged pixel: 32 data + 16 pad (96 B: the 16 pixels x 4 k-groups of one
                            // ds_read_b128 / ds_read_b64_tr_b16 instruction land on distinct 16-B slots)
 
 // Per-(cz, kc) weight slab in the packed buffer / in LDS, padded so that 256 threads move it as a whole number
-// of 16-byte pieces each (unconditional loads: a partially initialised register array gets spilled).
+// of 16-byte pieces each.
 __host__ __device__ constexpr int ws_stride_halfs(int taps, int NT) { return ((taps * 4 * NT * 8 + 2047) / 2048) * 2048; }
 
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
 __device__ __forceinline__ bf16x4 cvt4(float4 v) {
     return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
 }
 __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
     return (bf16x8){(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
 }
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }          // even channel
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // odd channel
 
 // ---------------------------------------------------------------- weight packing (bf16)
 // wpack[cz][kc][tap][g][n][j] (g = 0..3, n = 0..NT-1, j = 0..7) = bf16(W[cout = cz*NT + n][ch = kc*32 + 8g + j][tap])
@@ -57,7 +66,8 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int cout_w, int ci
 }
 
 // ---------------------------------------------------------------- forward / input gradient
-template <int NB, int KS>
+// INB: the input activation tensor is stored as bf16.
+template <int NB, int KS, bool INB>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc,
                                                             int vec_ok) {
     constexpr int NT = NB * 16;
@@ -70,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
     constexpr int XITEMS = NPIX * 4;                          // (pixel, 8-channel group) pieces per chunk
     constexpr int XPER = (XITEMS + 255) / 256;
     constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread (exact)
+    constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;
@@ -94,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack) + (size_t)cz * nkc * WS_HALFS;
-    const float* in = d.in + d.in_coff;
+    const float* in32 = d.in + d.in_coff;
+    const __bf16* in16 = reinterpret_cast<const __bf16*>(d.in) + d.in_coff;
 
     // Per-thread element offsets of the activation pieces (chunk independent).  Out-of-image pieces point at
     // element 0 and are zeroed by a select, so every load below is unconditional (no branches, no spills).
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
         xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld + 8 * (item & 3)) : 0u;
     }
     const int chg = 8 * (tid & 3);                            // channel group of this thread's pieces (256 % 4 == 0)
-    float4 xr[XPER][2];
+    u32x4 xr[XPER][XREGS];
     u32x4 wr[WPER];
 
     bool cv0 = false, cv1 = false;                            // channel validity of the chunk held in xr
@@ -118,25 +130,33 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
         const int ch = kc * KCB + chg;
         cv0 = ch < d.cin;
         cv1 = ch + 4 < d.cin;
-        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;   // invalid -> element 0 of the pixel slice
+        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;   // invalid -> element 0 of the slice
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
-            xr[k][0] = ld4(in + xoff[k] + (xok[k] ? o0 : 0));
-            xr[k][1] = ld4(in + xoff[k] + (xok[k] ? o1 : 0));
+            if constexpr (INB) {
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in16 + xoff[k] + (xok[k] ? o0 : 0));
+            } else {
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in32 + xoff[k] + (xok[k] ? o0 : 0));
+                xr[k][XREGS - 1] = *reinterpret_cast<const u32x4*>(in32 + xoff[k] + (xok[k] ? o1 : 0));
+            }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
 #pragma unroll
         for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
     };
     auto commit = [&]() {
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
             const bool v0 = xok[k] && cv0, v1 = xok[k] && cv1;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < XITEMS)
-                *reinterpret_cast<bf16x8*>(xs + (item >> 2) * XSB + 8 * (item & 3)) =
-                    cvt8(v0 ? xr[k][0] : z, v1 ? xr[k][1] : z);
+            if (item < XITEMS) {
+                __bf16* dst = xs + (item >> 2) * XSB + 8 * (item & 3);
+                if constexpr (INB)                           // cin % 8 == 0: a piece is valid or invalid as a whole
+                    *reinterpret_cast<u32x4*>(dst) = v0 ? xr[k][0] : z;
+                else
+                    *reinterpret_cast<bf16x8*>(dst) = cvt8(as_f4(v0 ? xr[k][0] : z), as_f4(v1 ? xr[k][XREGS - 1] : z));
+            }
         }
 #pragma unroll
         for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
@@ -178,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
 // transposed, i.e. exactly the k-major operand the MFMA wants.  k order inside a row: group g, element e
 // -> x = 4g + e (e < 4), 16 + 4g + e - 4 (e >= 4), identical for both operands, so that the two 16-lane
 // groups of a 32-lane half read 8 consecutive pixels = 8 distinct 32-B bank ranges.
-template <int KS>
+// XB / YB: x / dy are stored as bf16.  Staging pieces are 16 bytes: 4 fp32 or 8 bf16 channels.
+template <int KS, bool XB, bool YB>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc d, int tilesX, int tilesY,
                                                              int ntiles, int nci, int nco) {
     constexpr int HALO = KS / 2;
@@ -186,9 +207,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     constexpr int HW_ = TW + 2 * HALO;
     constexpr int HH_ = TH + 2 * HALO;
     constexpr int NPIX = HW_ * HH_;
-    constexpr int XITEMS = NPIX * 8;                 // float4 pieces of the X halo tile (32 ch)
+    constexpr int XPP = XB ? 4 : 8;                  // 16-byte pieces per pixel of the 32-channel X chunk
+    constexpr int YPP = YB ? 4 : 8;
+    constexpr int XCH = 32 / XPP, YCH = 32 / YPP;    // channels per piece
+    constexpr int XITEMS = NPIX * XPP;
     constexpr int XPER = (XITEMS + 255) / 256;
-    constexpr int YPER = TH * TW * 8 / 256;          // float4 pieces of the dY tile per thread
+    constexpr int YPER = TH * TW * YPP / 256;
     __shared__ __attribute__((aligned(16))) __bf16 lds[(NPIX + TH * TW) * XSB];
     __bf16* xs = lds;
     __bf16* dys = lds + NPIX * XSB;
@@ -202,18 +226,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     const int cib = wave >> 1, cob = wave & 1;
     const int cic = blockIdx.y, coc = blockIdx.z;
     const int H = d.h, W = d.w;
-    const float* x = d.x + d.x_coff;
-    const float* dy = d.dy + d.dy_coff;
+    const float* x32 = d.x + d.x_coff;
+    const __bf16* x16 = reinterpret_cast<const __bf16*>(d.x) + d.x_coff;
+    const float* dy32 = d.dy + d.dy_coff;
+    const __bf16* dy16 = reinterpret_cast<const __bf16*>(d.dy) + d.dy_coff;
 
     f32x4 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 xr[XPER], yr[YPER];
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // fp32 column sums of dy (bias gradient), channels 4*(tid&7)..+3
-    const int q4 = 4 * (tid & 7);                    // channel offset of this thread's pieces inside the chunk
-    const bool xch_ok = cic * WG_C + q4 < d.cin;
-    const int ych = coc * WG_C + q4;
+    u32x4 xr[XPER], yr[YPER];
+    // fp32 column sums of dy (bias gradient): channels yq..yq+3 in bsumA, yq+4..yq+7 in bsumB (bf16 pieces only)
+    float4 bsumA = make_float4(0.f, 0.f, 0.f, 0.f), bsumB = bsumA;
+    const int xq = XCH * (tid & (XPP - 1));          // channel offset of this thread's X pieces inside the chunk
+    const int yq = YCH * (tid & (YPP - 1));
+    const bool xch_ok = cic * WG_C + xq < d.cin;
+    const int ych = coc * WG_C + yq;
     const bool ych_ok = ych < d.cout;
     // all loads unconditional (invalid pieces read element 0 of the slice); the validity masks are applied in
     // commit(), so that nothing between the prefetch and the next commit uses a loaded value
@@ -227,40 +255,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
-            const int hp = item >> 3;
+            const int hp = item / XPP;
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
             const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch_ok;
             xmask |= (ok ? 1u : 0u) << k;
-            xr[k] = ld4(x + (ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * WG_C + q4 : 0));
+            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * WG_C + xq : 0;
+            if constexpr (XB) xr[k] = *reinterpret_cast<const u32x4*>(x16 + off);
+            else xr[k] = *reinterpret_cast<const u32x4*>(x32 + off);
         }
 #pragma unroll
         for (int k = 0; k < YPER; ++k) {
             const int item = tid + k * 256;
-            const int pp = item >> 3;
+            const int pp = item / YPP;
             const int py = pp / TW, px = pp - py * TW;
             const int gy = ty * TH + py, gx = tx * TW + px;
-            // the dy slice is readable up to a multiple of 4 channels (checked on the host); channels >= cout
-            // only feed partial sums that are never written
+            // the dy slice is readable up to a multiple of 4 (fp32) / 8 (bf16) channels (checked on the host);
+            // channels >= cout only feed partial sums that are never written
             const bool ok = gy < H && gx < W && ych_ok;
             ymask |= (ok ? 1u : 0u) << k;
-            yr[k] = ld4(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0));
+            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0;
+            if constexpr (YB) yr[k] = *reinterpret_cast<const u32x4*>(dy16 + off);
+            else yr[k] = *reinterpret_cast<const u32x4*>(dy32 + off);
         }
     };
     auto commit = [&]() {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
-            if (item < XITEMS)
-                *reinterpret_cast<bf16x4*>(xs + (item >> 3) * XSB + 4 * (item & 7)) = cvt4((xmask >> k) & 1 ? xr[k] : z);
+            if (item < XITEMS) {
+                const u32x4 v = (xmask >> k) & 1 ? xr[k] : z;
+                __bf16* dst = xs + (item / XPP) * XSB + XCH * (item & (XPP - 1));
+                if constexpr (XB) *reinterpret_cast<u32x4*>(dst) = v;
+                else *reinterpret_cast<bf16x4*>(dst) = cvt4(as_f4(v));
+            }
         }
 #pragma unroll
         for (int k = 0; k < YPER; ++k) {
             const int item = tid + k * 256;
-            const float4 v = (ymask >> k) & 1 ? yr[k] : z;
-            *reinterpret_cast<bf16x4*>(dys + (item >> 3) * XSB + 4 * (item & 7)) = cvt4(v);
-            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;   // bias column sums, unrounded values
+            const u32x4 v = (ymask >> k) & 1 ? yr[k] : z;
+            __bf16* dst = dys + (item / YPP) * XSB + YCH * (item & (YPP - 1));
+            if constexpr (YB) {
+                *reinterpret_cast<u32x4*>(dst) = v;           // word w holds channels 2w (low half), 2w+1 (high half)
+                bsumA.x += bf_lo(v[0]); bsumA.y += bf_hi(v[0]); bsumA.z += bf_lo(v[1]); bsumA.w += bf_hi(v[1]);
+                bsumB.x += bf_lo(v[2]); bsumB.y += bf_hi(v[2]); bsumB.z += bf_lo(v[3]); bsumB.w += bf_hi(v[3]);
+            } else {
+                const float4 f = as_f4(v);
+                *reinterpret_cast<bf16x4*>(dst) = cvt4(f);
+                bsumA.x += f.x; bsumA.y += f.y; bsumA.z += f.z; bsumA.w += f.w;   // unrounded values
+            }
         }
     };
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -300,7 +344,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
-    wgrad_bias_partial(d, bsum, reinterpret_cast<float*>(lds), nco, cic, coc);
+
+    // bias partials: thread t's sums cover channels yq..yq+YCH-1 of the co chunk, pieces repeat every YPP threads
+    if (cic == 0 && d.dbias != nullptr) {                    // uniform per workgroup
+        float* scratch = reinterpret_cast<float*>(lds);      // 256 x 8 floats
+        __syncthreads();
+        st4(scratch + 8 * tid, bsumA);
+        st4(scratch + 8 * tid + 4, bsumB);
+        __syncthreads();
+        if (tid < 32) {
+            const int piece = tid / YCH, e = tid % YCH;      // channel `tid` of the chunk
+            float s = 0.f;
+            for (int k = 0; k < 256 / YPP; ++k) s += scratch[8 * (YPP * k + piece) + e];
+            float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+            bp[((size_t)blockIdx.x * nco + coc) * WG_C + tid] = s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- host side
@@ -329,8 +388,13 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int nkc = (d.cin + KCB - 1) / KCB;
     const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
-#define NVQ_LAUNCH_CONVB(NB, KS) \
-    hipLaunchKernelGGL((conv_bf16_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
+#define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
+    do {                                                                                                                 \
+        if (d.in_bf16)                                                                                                   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok);   \
+        else                                                                                                             \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok);  \
+    } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);
         else if (NT == 32) NVQ_LAUNCH_CONVB(2, 3);
@@ -347,10 +411,20 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s) {
     const dim3 grid(nsplit, nci, nco);
-    if (d.ksize == 3)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<3>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
-    else
-        hipLaunchKernelGGL((wgrad_bf16_kernel<1>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
+#define NVQ_LAUNCH_WG(KS, XB, YB) \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<KS, XB, YB>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco)
+    if (d.ksize == 3) {
+        if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(3, true, true);
+        else if (d.x_bf16) NVQ_LAUNCH_WG(3, true, false);
+        else if (d.dy_bf16) NVQ_LAUNCH_WG(3, false, true);
+        else NVQ_LAUNCH_WG(3, false, false);
+    } else {
+        if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(1, true, true);
+        else if (d.x_bf16) NVQ_LAUNCH_WG(1, true, false);
+        else if (d.dy_bf16) NVQ_LAUNCH_WG(1, false, true);
+        else NVQ_LAUNCH_WG(1, false, false);
+    }
+#undef NVQ_LAUNCH_WG
     return check_launch("conv_wgrad_bf16");
 }
 

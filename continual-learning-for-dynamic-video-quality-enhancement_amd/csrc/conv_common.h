@@ -4,6 +4,25 @@
 
 namespace nvq {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels at element index `idx` of an fp32 or bf16 activation buffer
+__device__ __forceinline__ float4 ldx4(const float* base, size_t idx, int is_bf16) {
+    if (is_bf16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    return ld4(base + idx);
+}
+__device__ __forceinline__ void stx4(float* base, size_t idx, int is_bf16, float4 v) {
+    if (is_bf16)
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) =
+            (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    else
+        st4(base + idx, v);
+}
+
 constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
@@ -68,24 +87,25 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= d.alpha;
-                if (d.out2) st4(d.out2 + pix * d.out2_ld + d.out2_coff + co, make_float4(v[0], v[1], v[2], v[3]));
+                if (d.out2)
+                    stx4(d.out2, pix * d.out2_ld + d.out2_coff + co, d.out2_bf16, make_float4(v[0], v[1], v[2], v[3]));
                 if (d.res && co < d.res_cmax) {
-                    const float4 r = ld4(d.res + pix * d.res_ld + d.res_coff + co);
+                    const float4 r = ldx4(d.res, pix * d.res_ld + d.res_coff + co, d.res_bf16);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
-                float* op = d.out + pix * d.out_ld + d.out_coff + co;
+                const size_t oi = pix * d.out_ld + d.out_coff + co;
                 if (d.accumulate) {
-                    const float4 o = ld4(op);
+                    const float4 o = ldx4(d.out, oi, d.out_bf16);
                     v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
                 if (d.mask && co >= d.mask_c0 && co < d.mask_c1) {
-                    const float4 m = ld4(d.mask + pix * d.mask_ld + d.mask_coff + co);
+                    const float4 m = ldx4(d.mask, pix * d.mask_ld + d.mask_coff + co, d.mask_bf16);
                     if (!(m.x > 0.f)) v[0] = 0.f;
                     if (!(m.y > 0.f)) v[1] = 0.f;
                     if (!(m.z > 0.f)) v[2] = 0.f;
                     if (!(m.w > 0.f)) v[3] = 0.f;
                 }
-                st4(op, make_float4(v[0], v[1], v[2], v[3]));
+                stx4(d.out, oi, d.out_bf16, make_float4(v[0], v[1], v[2], v[3]));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -447,6 +447,11 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
         vec_ok = 0;
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
     hipStream_t s = (hipStream_t)stream;
+    const int epi_bf16 = d.out_bf16 | d.out2_bf16 | d.res_bf16 | d.mask_bf16;
+    NVQ_REQUIRE(!(epi_bf16 | d.in_bf16) || d.math == NVQ_MATH_BF16, "conv_forward: bf16 tensors need NVQ_MATH_BF16");
+    NVQ_REQUIRE(!epi_bf16 || vec_ok, "conv_forward: bf16 output / residual / mask tensors need 4-channel aligned slices");
+    NVQ_REQUIRE(!d.in_bf16 || (d.cin % 8 == 0 && d.in_ld % 8 == 0 && d.in_coff % 8 == 0),
+                "conv_forward: a bf16 input needs cin, ld, coff %% 8 == 0 (cin %d ld %d coff %d)", d.cin, d.in_ld, d.in_coff);
     if (d.math == NVQ_MATH_BF16) return conv_forward_bf16(d, vec_ok, s);
 #define NVQ_LAUNCH_CONV(NB, KS) \
     hipLaunchKernelGGL((conv_f32_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
@@ -476,6 +481,9 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     NVQ_REQUIRE(d.dy_ld % 4 == 0 && d.dy_coff % 4 == 0 && aligned16(d.dy),
                 "conv_wgrad: dy must be 16-byte addressable");
     NVQ_REQUIRE(d.cin_w > 0 && d.cin_w <= d.cin && d.cout > 0, "conv_wgrad: channels");
+    NVQ_REQUIRE(!(d.x_bf16 | d.dy_bf16) || d.math == NVQ_MATH_BF16, "conv_wgrad: bf16 tensors need NVQ_MATH_BF16");
+    NVQ_REQUIRE(!d.x_bf16 || (d.cin % 8 == 0 && d.x_ld % 8 == 0 && d.x_coff % 8 == 0), "conv_wgrad: bf16 x alignment");
+    NVQ_REQUIRE(!d.dy_bf16 || (d.cout % 8 == 0 && d.dy_ld % 8 == 0 && d.dy_coff % 8 == 0), "conv_wgrad: bf16 dy alignment");
     NVQ_REQUIRE(d.math != NVQ_MATH_BF16 || d.dy_coff + ((d.cout + 3) & ~3) <= d.dy_ld,
                 "conv_wgrad(bf16): the dy slice must be readable up to a multiple of 4 channels");
     NVQ_REQUIRE(d.workspace_bytes >= nvq_wgrad_workspace_bytes(), "conv_wgrad: workspace too small");

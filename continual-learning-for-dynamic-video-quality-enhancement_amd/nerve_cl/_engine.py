@@ -69,13 +69,18 @@ class Saved:
 
 
 def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: int, scale: int,
-            training: bool, math: int = K.MATH_F32) -> "tuple[torch.Tensor, Saved]":
+            training: bool, math: int = K.MATH_F32, act_dtype: torch.dtype = torch.float32
+            ) -> "tuple[torch.Tensor, Saved]":
+    """act_dtype: storage type of the conv-internal tensors (dense-block concat buffers, flow-net and attention
+    hidden activations and, in backward, their gradients).  torch.bfloat16 needs math == MATH_BF16; every
+    tensor a non-conv kernel touches stays fp32."""
+    assert act_dtype == torch.float32 or math == K.MATH_BF16
     g = Geometry(frames, F, nblocks, scale)
     dev = frames.device
     B, T, H, W, NI, NO, c = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c
     ws = workspace(dev)
     sv = Saved()
-    sv.g, sv.frames, sv.training, sv.math = g, frames, training, math
+    sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
 
     # ---- feature extractor, all T frames in one batch (slot order)
     feat0 = _new(dev, NI, H, W, F)
@@ -122,7 +127,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             w = P[f"motion_estimator.flow_net.{idx}.weight"]
             wp = K.conv_pack(w, False, x.c, math=math)
             last = idx == 6
-            y = _new(dev, NO, H, W, K.pad4(chans[li + 1]))
+            y = _new(dev, NO, H, W, K.pad4(chans[li + 1]), dtype=torch.float32 if last else act_dtype)
             K.conv_forward(x, wp, P[f"motion_estimator.flow_net.{idx}.bias"], Sl(y, chans[li + 1]), 3,
                            relu=not last, cout_store=K.pad4(chans[li + 1]), math=math)
             sv.flow_acts.append(y)
@@ -134,7 +139,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sv.flow = sv.flow_acts[-1] if NO else None
 
     # ---- temporal aggregation
-    a1, a2 = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
+    a1, a2 = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)
     logits = _new(dev, B, H, W, g.Tp)
     K.conv_forward(Sl(aligned), K.conv_pack(P["temporal_aggregator.attention.0.weight"], False, T * F, math=math),
                    P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math)
@@ -153,7 +158,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     K.cbam_channel(gap_partial, nblk, F, g.R, B, H * W, w1, w2, gap, hid, ca)
     sm, amax, sa = _new(dev, B, H, W, 2), _new(dev, B, H, W, dtype=torch.int32), _new(dev, B, H, W)
     K.cbam_pool(weighted, ca, sm, amax)
-    cats = [_new(dev, B, H, W, g.CAT) for _ in range(nblocks)]
+    cats = [_new(dev, B, H, W, g.CAT, dtype=act_dtype) for _ in range(nblocks)]
     resout = _new(dev, B, H, W, F)
 
     def xloc(k):  # where the input of block k / the output of block k-1 lives
@@ -200,7 +205,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     g = sv.g
     dev = dout.device
     B, T, H, W, NI, NO, c, F = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c, g.F
-    math = sv.math
+    math, act_dtype = sv.math, sv.act_dtype
     ws = workspace(dev)
     nb = g.NB
 
@@ -217,12 +222,12 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
     # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
-    dcats = [_new(dev, B, H, W, g.CAT), _new(dev, B, H, W, g.CAT)] if nb else []
+    dcats = [_new(dev, B, H, W, g.CAT, dtype=act_dtype), _new(dev, B, H, W, g.CAT, dtype=act_dtype)] if nb else []
     dagg = _new(dev, B, H, W, F)
     gout = Sl(dcats[(nb - 1) & 1], F, 0) if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
     _capture("dfused", dfeat_c)
-    _capture("dres", gout.t[..., :F])
+    _capture("dres", gout.t[..., :F].float())
 
     # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
     for k in range(nb - 1, -1, -1):
@@ -244,7 +249,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         K.conv_forward(Sl(dcat), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
     dprev = Sl(dagg)
 
-    _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F])
+    _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F].float())
     # ---- CBAM
     w1 = P["temporal_aggregator.refine.channel_attention.fc.0.weight"]
     w2 = P["temporal_aggregator.refine.channel_attention.fc.2.weight"]
@@ -267,11 +272,11 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.tsum_backward(dweighted, dgap_pix, sv.aligned, sv.attn, T, F, daligned, dlogits)
     pre = "temporal_aggregator.attention."
     _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", ws, 3, math=math)
-    da2 = _new(dev, B, H, W, F)
+    da2 = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(dlogits), K.conv_pack(P[pre + "4.weight"], True, g.Tp, F, math=math), None, Sl(da2), 3,
                    mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
-    da1 = _new(dev, B, H, W, F)
+    da1 = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(da2), K.conv_pack(P[pre + "2.weight"], True, F, F, math=math), None, Sl(da1), 3,
                    mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
@@ -300,7 +305,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             _wgrad(Sl(x_t), chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
             cin_store = dy_t.shape[-1]
             wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li], math=math)
-            dx_t = _new(dev, NO, H, W, x_t.shape[-1])
+            dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else torch.float32)
             if li > 0:
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
                                mask_c1=chans[li], math=math)
@@ -340,7 +345,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
 
 def nhwc_to_nchw(t: torch.Tensor, c: Optional[int] = None, coff: int = 0) -> torch.Tensor:
     c = t.shape[-1] - coff if c is None else c
-    return t[..., coff:coff + c].permute(0, 3, 1, 2).contiguous()
+    return t[..., coff:coff + c].permute(0, 3, 1, 2).contiguous().float()
 
 
 def intermediates(sv: Saved) -> dict:

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("alpha", cf),
         ("accumulate", ci),
         ("math", ci),
+        ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
     ]
 
 
@@ -51,6 +52,7 @@ class WgradDesc(C.Structure):
         ("workspace", vp), ("workspace_bytes", sz),
         ("n", ci), ("h", ci), ("w", ci), ("ksize", ci),
         ("alpha", cf), ("accumulate", ci), ("math", ci),
+        ("x_bf16", ci), ("dy_bf16", ci),
     ]
 
 
@@ -86,7 +88,7 @@ SIGNATURES = {
     "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "nvq_cbam_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]),
-    "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp]),
     "nvq_cbam_bwd_spatial_pre": (ci, [vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
     "nvq_cbam_bwd_spatial_conv": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, sz, ci, vp]),
     "nvq_cbam_bwd_scale": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
@@ -151,12 +153,13 @@ def int_array(vals: Sequence[int]):
 
 
 class Sl:
-    """A channel slice of an fp32 NHWC buffer: tensor [N,H,W,ld], channels [coff, coff+c)."""
+    """A channel slice of an NHWC activation buffer (fp32, or bf16 for conv-internal tensors):
+    tensor [N,H,W,ld], channels [coff, coff+c); ld / coff count elements of the tensor's dtype."""
 
     __slots__ = ("t", "ld", "coff", "c")
 
     def __init__(self, t: torch.Tensor, c: Optional[int] = None, coff: int = 0):
-        assert t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()
+        assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.is_contiguous()
         self.t, self.ld, self.coff = t, t.shape[-1], coff
         self.c = t.shape[-1] - coff if c is None else c
         assert self.coff + self.c <= self.ld
@@ -164,6 +167,10 @@ class Sl:
     @property
     def n(self):
         return self.t.shape[0]
+
+    @property
+    def bf16(self) -> int:
+        return int(self.t.dtype == torch.bfloat16)
 
     def images(self, lo: int, hi: int) -> "Sl":
         return Sl(self.t[lo:hi], self.c, self.coff)
@@ -268,13 +275,20 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
         d.mask, d.mask_ld, d.mask_coff, d.mask_c0, d.mask_c1 = ptr(mask.t), mask.ld, mask.coff, mask_c0, mask_c1
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.relu, d.alpha, d.accumulate, d.math = int(relu), alpha, int(accumulate), math
+    d.in_bf16, d.out_bf16 = x.bf16, out.bf16
+    d.out2_bf16 = out2.bf16 if out2 is not None else 0
+    d.res_bf16 = res.bf16 if res is not None else 0
+    d.mask_bf16 = mask.bf16 if mask is not None else 0
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
     if ev0 is not None:
         cin = x.c if alg_cin is None else alg_cin
-        planes = cin + out.c + (res.c if res is not None else 0) + (out.c if accumulate else 0) \
-            + (out2.c if out2 is not None else 0) + ((mask_c1 - mask_c0) if mask is not None else 0)
+        esz = lambda sl: 2.0 if sl.bf16 else 4.0   # noqa: E731  bytes per element
+        nbytes = cin * esz(x) + out.c * esz(out) * (2 if accumulate else 1) \
+            + (res.c * esz(res) if res is not None else 0) + (out2.c * esz(out2) if out2 is not None else 0) \
+            + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0)
         TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
-                   4.0 * n * h * w * planes, f"n{n} cin{x.c} cout{out.c}" + (" acc" if accumulate else "")
+                   n * h * w * nbytes, f"n{n} cin{x.c}{'h' if x.bf16 else ''} cout{out.c}{'h' if out.bf16 else ''}"
+                   + (" acc" if accumulate else "")
                    + (" res" if res is not None else "") + (" mask" if mask is not None else ""))
 
 
@@ -305,10 +319,12 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.workspace, d.workspace_bytes = ptr(ws), ws.numel() * ws.element_size()
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
+    d.x_bf16, d.dy_bf16 = x.bf16, dy.bf16
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
         TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
-                   4.0 * n * h * w * (cin_w + dy.c), f"n{n} cin{cin_w} cout{dy.c}")
+                   n * h * w * (cin_w * (2.0 if x.bf16 else 4.0) + dy.c * (2.0 if dy.bf16 else 4.0)),
+                   f"n{n} cin{cin_w}{'h' if x.bf16 else ''} cout{dy.c}{'h' if dy.bf16 else ''}")
 
 
 # ----------------------------------------------------------------------------- feature extractor
@@ -436,7 +452,7 @@ def cbam_pool(x: torch.Tensor, ca, sm, amax):
 def cbam_spatial_apply(x: torch.Tensor, ca, sm, w7, sa, out: Sl):
     N, H, W, ld = x.shape
     check(lib().nvq_cbam_spatial_apply(ptr(x), ld, ptr(ca), ptr(sm), ptr(w7), ca.shape[-1], N, H, W, ptr(sa),
-                                       ptr(out.t), out.ld, out.coff, stream()), "nvq_cbam_spatial_apply")
+                                       ptr(out.t), out.ld, out.coff, out.bf16, stream()), "nvq_cbam_spatial_apply")
 
 
 def cbam_bwd_spatial_pre(dout: Sl, x: torch.Tensor, ca, sa, dpre):

@@ -79,7 +79,8 @@ class _SRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: "SuperResolutionNet", frames: torch.Tensor, want_inter: bool, *params):
         P = net._tensor_dict()
-        out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode)
+        act = torch.bfloat16 if (net.bf16_activations and net.math_mode == _nvq.MATH_BF16) else torch.float32
+        out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode, act)
         need_grad = any(ctx.needs_input_grad[3:])
         ctx.net = net
         ctx.sv = sv if need_grad else None
@@ -130,7 +131,12 @@ class SuperResolutionNet(nn.Module):
         self.upsampler = PixelShuffleUpsampler(num_features, scale_factor, in_channels)
         self.bicubic_upsample = Act()   # nn.Upsample(bicubic) in the reference; fused into the tail kernel
 
+        # Precision knobs (not part of the reference surface).  math_mode: MFMA operand type of the convolutions
+        # (fp32 = the parity mode, 1e-3 of the CPU path; bf16 = the throughput mode of BASELINE cfg2).
+        # bf16_activations: additionally store the conv-internal tensors (dense-block buffers, flow-net and
+        # attention hidden activations, their gradients) as bf16; only honoured with math_mode = MATH_BF16.
         self.math_mode = _nvq.MATH_F32
+        self.bf16_activations = False
         self._param_names: List[str] = [n for n, _ in self.named_parameters()]
         self._grad_bucket_hook = None
         self._last_intermediates = None

@@ -79,6 +79,10 @@ typedef struct nvq_conv_desc {
     float alpha;      /* scale after relu */
     int accumulate;   /* out += result */
     int math;         /* NVQ_MATH_* */
+    /* Storage type of each activation tensor: 0 = fp32, 1 = bf16 (ld / coff then count bf16 elements and the
+     * pointer, although typed float*, addresses bf16 data).  bf16 tensors need NVQ_MATH_BF16, a bf16 input
+     * needs cin, in_ld, in_coff % 8 == 0, and every slice must be 8-byte addressable. */
+    int in_bf16, out_bf16, out2_bf16, res_bf16, mask_bf16;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
@@ -107,6 +111,7 @@ typedef struct nvq_wgrad_desc {
     float* workspace; size_t workspace_bytes;
     int n, h, w, ksize;
     float alpha; int accumulate; int math;
+    int x_bf16, dy_bf16;                /* storage type of x / dy (see nvq_conv_desc); need NVQ_MATH_BF16 */
 } nvq_wgrad_desc;
 size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */
 int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);
@@ -223,10 +228,11 @@ int nvq_cbam_channel(const float* gap_partial, int nblk, int C, int R, int N, in
 /* sm[n,p,0] = mean_c(x*ca), sm[n,p,1] = max_c(x*ca); amax = argmax channel. sm ld = 2. */
 int nvq_cbam_pool(const float* x, int x_ld, const float* ca, int C, int N, int H, int W,
                   float* sm, int* amax, void* stream);
-/* sa = sigmoid(conv7x7(sm; w[1][2][7][7], pad 3)); out = x*ca*sa written at (out,ld,coff). */
+/* sa = sigmoid(conv7x7(sm; w[1][2][7][7], pad 3)); out = x*ca*sa written at (out,ld,coff); out_bf16 != 0
+ * stores bf16 (the destination is the first dense block's concat buffer). */
 int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const float* sm,
                            const float* w7, int C, int N, int H, int W, float* sa,
-                           float* out, int out_ld, int out_coff, void* stream);
+                           float* out, int out_ld, int out_coff, int out_bf16, void* stream);
 /* Backward through out = x*ca*sa:
  * step1: dpre[n,p] = (sum_c dout*x*ca) * sa*(1-sa)                                   */
 int nvq_cbam_bwd_spatial_pre(const float* dout, int dout_ld, int dout_coff, const float* x,

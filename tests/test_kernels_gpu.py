@@ -495,3 +495,70 @@ def test_conv_bf16_weight_gradient(K, cin, cin_store, cout, k, N, H, W):
                  math=K.MATH_BF16)
     assert rel(dw, w.grad) < TOL
     assert rel(db, dy.sum((0, 2, 3))) < TOL      # bias gradient is summed in fp32 from the unrounded dy
+
+
+# ----------------------------------------------------------------------------- bf16-STORED activation tensors
+def to_nhwc_bf16(x, ld=None, coff=0):
+    return to_nhwc(x, ld, coff).bfloat16()
+
+
+@pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 13, 37), (224, 64, 1, 1, 11, 40), (192, 32, 3, 1, 8, 35),
+                                              (128, 64, 3, 1, 9, 33), (32, 2, 3, 1, 8, 32)])
+def test_conv_bf16_stored_input_and_output(K, cin, cout, k, N, H, W):
+    """Input read as stored bf16 (no rounding in the kernel), output written as bf16 (rounded once) or fp32."""
+    x, w, b = bf(rnd(N, cin, H, W)), rnd(cout, cin, k, k, scale=0.2), rnd(cout)
+    ref = F.relu(F.conv2d(x, bf(w), b, padding=k // 2))
+    wp = K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16)
+    xin = to_nhwc_bf16(x)
+    cst = K.pad4(cout)
+    out32 = torch.zeros(N, H, W, cst, device="cuda")
+    K.conv_forward(K.Sl(xin), wp, b.cuda(), K.Sl(out32, cout, 0), k, relu=True, cout_store=cst, math=K.MATH_BF16)
+    assert rel(from_nhwc(out32, cout), ref) < TOL
+    if cout % 8 == 0:
+        out16 = torch.zeros(N, H, W, cout + 8, device="cuda", dtype=torch.bfloat16)
+        K.conv_forward(K.Sl(xin), wp, b.cuda(), K.Sl(out16, cout, 8), k, relu=True, math=K.MATH_BF16)
+        assert torch.equal(out16[..., 8:].float().cpu(), to_nhwc(ref).bfloat16().float().cpu()) or \
+            rel(out16[..., 8:].float().permute(0, 3, 1, 2), ref) < 5e-3       # one bf16 rounding of the result
+        assert out16[..., :8].abs().max().item() == 0
+
+
+def test_conv_bf16_stored_dense_block_epilogues(K):
+    """All tensors bf16: in-place concat write, lff form (scale + residual), mask + second output."""
+    N, H, W, Fc, CAT = 1, 10, 33, 64, 224
+    cat = bf(rnd(N, CAT, H, W))
+    w3, b3 = rnd(32, 96, 3, 3, scale=0.1), rnd(32)
+    catb = to_nhwc_bf16(cat)
+    K.conv_forward(K.Sl(catb, 96, 0), K.conv_pack(w3.cuda(), False, 96, math=K.MATH_BF16), b3.cuda(), K.Sl(catb, 32, 96), 3,
+                   relu=True, math=K.MATH_BF16)
+    ref3 = F.relu(F.conv2d(cat[:, :96], bf(w3), b3, padding=1))
+    assert rel(catb[..., 96:128].float().permute(0, 3, 1, 2), ref3) < 5e-3
+    assert torch.equal(catb[..., :96].float().cpu(), to_nhwc(cat[:, :96]).cpu())
+    w1, b1 = rnd(Fc, CAT, 1, 1, scale=0.1), rnd(Fc)
+    cat2 = to_nhwc_bf16(cat)
+    nxt = torch.zeros(N, H, W, CAT, device="cuda", dtype=torch.bfloat16)
+    K.conv_forward(K.Sl(cat2), K.conv_pack(w1.cuda(), False, CAT, math=K.MATH_BF16), b1.cuda(), K.Sl(nxt, Fc, 0), 1,
+                   alpha=0.2, res=K.Sl(cat2, Fc, 0), math=K.MATH_BF16)
+    ref1 = F.conv2d(cat, bf(w1), b1) * 0.2 + cat[:, :Fc]
+    assert rel(nxt[..., :Fc].float().permute(0, 3, 1, 2), ref1) < 5e-3
+    # mirror-backward form: bf16 gradient buffer, mask from the bf16 forward buffer at another channel offset
+    dcat = to_nhwc_bf16(bf(rnd(N, CAT, H, W, seed=5)))
+    wb = rnd(32, 128, 3, 3, scale=0.1)
+    K.conv_forward(K.Sl(dcat, 128, 0), K.conv_pack(wb.cuda(), False, 128, math=K.MATH_BF16), None, K.Sl(dcat, 32, 128), 3,
+                   mask=K.Sl(cat2, 32, 96), mask_c0=0, mask_c1=32, math=K.MATH_BF16)
+    refb = F.conv2d(dcat[..., :128].float().permute(0, 3, 1, 2).cpu(), bf(wb), None, padding=1) * (cat[:, 96:128] > 0)
+    assert rel(dcat[..., 128:160].float().permute(0, 3, 1, 2), refb) < 5e-3
+
+
+@pytest.mark.parametrize("xb,yb", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 16, 40), (224, 64, 1, 1, 11, 37), (192, 64, 3, 1, 8, 64)])
+def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
+    x, dy = bf(rnd(N, cin, H, W)), bf(rnd(N, cout, H, W, seed=3))
+    w = rnd(cout, cin, k, k).requires_grad_()
+    F.conv2d(x, w, None, padding=k // 2).backward(dy)
+    dw = torch.zeros(cout, cin, k, k, device="cuda")
+    db = torch.zeros(cout, device="cuda")
+    xs = to_nhwc_bf16(x) if xb else to_nhwc(x)
+    ds = to_nhwc_bf16(dy, cout + 8, 8) if yb else to_nhwc(dy, cout + 8, 8)
+    K.conv_wgrad(K.Sl(xs), cin, K.Sl(ds, cout, 8), dw, db, ws_tensor(K), k, math=K.MATH_BF16)
+    assert rel(dw, w.grad) < TOL
+    assert rel(db, dy.sum((0, 2, 3))) < TOL

@@ -243,3 +243,44 @@ def test_bf16_math_mode_quality(SR):
     assert psnr > 45.0
     assert abs(loss.item() - o_loss.item()) < 2e-3 * o_loss.item()
     assert cos_min > 0.99
+
+
+def test_bf16_activation_storage_quality(SR):
+    """bf16 MFMA operands AND bf16 storage of the conv-internal tensors (dense-block buffers, flow-net and
+    attention hidden activations and their gradients): judged against the fp32 oracle like the test above."""
+    from nerve_cl import _nvq
+    net, ora = build_pair(SR, 32, 4, 1, 2, True)
+    net.math_mode, net.bf16_activations = _nvq.MATH_BF16, True
+    x = synth.formula_clip(2, 3, 64, 64, seed=3)
+    tgt = synth.formula_target(2, 128, 128, seed=4)
+    out, inter = net(x.cuda(), return_intermediate=True)
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    o_out = ora(x)
+    o_loss = F.mse_loss(o_out, tgt)
+    o_loss.backward()
+    psnr = sr_oracle.compute_psnr(out.detach().cpu(), o_out.detach())
+    onamed = ora.named()
+    cos_min, worst = 1.0, None
+    for n, p in net.named_parameters():
+        a, b = p.grad.detach().double().cpu().reshape(-1), onamed[n].grad.double().reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        if "motion_estimator" not in n and cos < cos_min:
+            cos_min, worst = cos, n
+    print(f"  bf16 storage: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, "
+          f"min grad cosine (non-flow tensors) {cos_min:.5f} at {worst}")
+    assert inter["aggregated"].dtype == torch.float32
+    assert psnr > 40.0
+    assert abs(loss.item() - o_loss.item()) < 5e-3 * o_loss.item()
+    assert cos_min > 0.98
+    # a few optimiser steps keep tracking the fp32 trajectory
+    net2, ora2 = build_pair(SR, 32, 4, 1, 2, True)
+    net2.math_mode, net2.bf16_activations = _nvq.MATH_BF16, True
+    o1 = torch.optim.AdamW(net2.parameters(), lr=1e-3, weight_decay=1e-5)
+    o2 = torch.optim.AdamW(ora2.parameters(), lr=1e-3, weight_decay=1e-5)
+    l1, l2 = [], []
+    for _ in range(3):
+        o1.zero_grad(); a = F.mse_loss(net2(x.cuda()), tgt.cuda()); a.backward(); o1.step(); l1.append(a.item())
+        o2.zero_grad(); b = F.mse_loss(ora2(x), tgt); b.backward(); o2.step(); l2.append(b.item())
+    print("  bf16 storage losses", l1, "fp32 oracle", l2)
+    assert np.allclose(l1, l2, rtol=1e-2)
