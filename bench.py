@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--scale", type=int, default=2)
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16",
                     help="MFMA operand precision of the convolutions (accumulation and storage are fp32)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--fp32-acts", action="store_true",
                     help="with --math bf16: keep the conv-internal tensors in fp32 (default: bf16 storage)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -114,7 +115,12 @@ def main():
     from nerve_cl import _nvq, parallel
     from nerve_cl.models import SuperResolutionNet
 
-    rank, world, local = parallel.init_from_env("nccl")
+    if args.backend != "nccl":
+        local_dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_dev)
+    rank, world, local = parallel.init_from_env(args.backend)
+    if args.backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",

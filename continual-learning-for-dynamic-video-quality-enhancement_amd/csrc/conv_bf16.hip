@@ -14,6 +14,11 @@
 
 namespace nvq {
 
+// Diagnostic switch (tools/kernel_phases.py only; 0 in every product path): 1 = skip the MFMA section,
+// 2 = skip the per-chunk global loads after the first chunk.  Results are wrong in both modes.
+static int g_debug_mode = 0;
+void set_conv_debug_mode(int m) { g_debug_mode = m; }
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece
 
@@ -69,7 +74,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int cout_w, int ci
 // INB: the input activation tensor is stored as bf16.
 template <int NB, int KS, bool INB>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc,
-                                                            int vec_ok) {
+                                                            int vec_ok, int dbg) {
     constexpr int NT = NB * 16;
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
@@ -167,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
         __syncthreads();
         commit();
         __syncthreads();
-        if (kc + 1 < nkc) fetch(kc + 1);
+        if (kc + 1 < nkc && dbg != 2) fetch(kc + 1);
+        if (dbg == 1) continue;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
@@ -391,9 +397,9 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
 #define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
     do {                                                                                                                 \
         if (d.in_bf16)                                                                                                   \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok);   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode);   \
         else                                                                                                             \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok);  \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode);  \
     } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);

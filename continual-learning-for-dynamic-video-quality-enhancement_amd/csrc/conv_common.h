@@ -30,6 +30,8 @@ constexpr int WGRAD_MAX_WG = 512;
 
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
+void set_conv_debug_mode(int m);
+
 // NVQ_MATH_BF16 variants (conv_bf16.hip)
 size_t pack_floats_bf16(int cout, int cin_store, int ksize);
 int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store, int cout_keep,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "nvq_conv_pack_floats": (sz, [ci, ci, ci, ci]),
     "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
+    "nvq_debug_set_conv_mode": (ci, [ci]),
     "nvq_rdb_backward_weights_floats": (sz, [ci]),
     "nvq_rdb_backward_weights": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "nvq_sizeof_conv_desc": (sz, []),

@@ -87,6 +87,9 @@ typedef struct nvq_conv_desc {
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
 int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
+/* Diagnostics only (tools/kernel_phases.py): 0 = normal; 1 = bf16 conv kernels skip the MFMA section;
+ * 2 = they skip the per-chunk global loads after the first chunk.  Results are wrong for mode != 0. */
+int nvq_debug_set_conv_mode(int mode);
 size_t nvq_sizeof_conv_desc(void);
 
 /* Combined weights for the backward of one ResidualDenseBlock (super_resolution.py:245-253) in "mirror"
