@@ -81,8 +81,15 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__
 
 // WHICH == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d]        * other[n % oi, p + off(d), c]
 // WHICH == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n,      q - off(d), c]
-// The displacement rows are a runtime loop (9 weights live in registers at a time): a fully
-// unrolled 81-tap body made the compiler hoist every LDS read and spill ~900 VGPRs.
+// Structure (each point was a measured stall):
+//  * the displacement rows are a runtime loop with 9 weights live at a time: a fully unrolled 81-tap body made
+//    the compiler hoist every LDS read and spill ~900 VGPRs;
+//  * the next row's 9 weights are loaded while the current row is computed (a row that starts by loading its
+//    own weights waits a full memory latency 36 times per tile);
+//  * the next channel chunk's halo pieces are fetched into registers during the compute of the current chunk.
+constexpr int CH_ITEMS = CHH * CHW * 4;                 // float4 pieces of one 16-channel halo chunk
+constexpr int CH_PER = (CH_ITEMS + 255) / 256;
+
 template <int WHICH>
 __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__ dcorr, int dcorr_ld,
                                                        const float* __restrict__ other, int other_ld,
@@ -94,47 +101,93 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
-    const int py = threadIdx.x / CT_W, px = threadIdx.x % CT_W;
+    const int tid = threadIdx.x;
+    const int py = tid / CT_W, px = tid % CT_W;
     const int gy = ty * CT_H + py, gx = tx * CT_W + px;
     const bool inside = gy < H && gx < W;
     const size_t pix = (size_t)(n * H + (inside ? gy : 0)) * W + (inside ? gx : 0);
     const float inv = 1.f / (float)C;
+    const int on = n % other_images;
+
+    // halo staging: per-thread piece offsets (chunk independent); invalid pieces read element 0, masked at commit
+    unsigned hoff[CH_PER];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int k = 0; k < CH_PER; ++k) {
+        const int item = tid + k * 256;
+        const int hp = item >> 2;
+        const int hy = hp / CHW, hx = hp - hy * CHW;
+        const int yy = ty * CT_H + hy - CD, xx = tx * CT_W + hx - CD;
+        const bool ok = item < CH_ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        hmask |= (ok ? 1u : 0u) << k;
+        hoff[k] = ok ? (unsigned)(((size_t)(on * H + yy) * W + xx) * other_ld + 4 * (item & 3)) : 0u;
+    }
+    const int cq = 4 * (tid & 3);
+    float4 hr[CH_PER];
+    bool hch = false;
+    auto fetch = [&](int ch0) {
+        hch = ch0 + cq < C;
+        const int o = hch ? ch0 : -cq;
+#pragma unroll
+        for (int k = 0; k < CH_PER; ++k) hr[k] = ld4(other + hoff[k] + ((hmask >> k) & 1 ? o : 0));
+    };
+    auto commit = [&]() {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < CH_PER; ++k) {
+            const int item = tid + k * 256;
+            if (item < CH_ITEMS) st4(xs + (item >> 2) * CLD + 4 * (item & 3), ((hmask >> k) & 1) && hch ? hr[k] : z);
+        }
+    };
+    // weights of displacement row i for this thread's pixel (addresses clamped, masked when used)
+    auto load_row = [&](int i, float (&w)[CN], unsigned& wm) {
+        wm = 0;
+        if (WHICH == 1) {
+#pragma unroll
+            for (int j = 0; j < CN; ++j) w[j] = dcorr[pix * dcorr_ld + i * CN + j];
+            wm = inside ? 0x1ffu : 0u;
+        } else {
+            const int qy = gy - (i - CD);
+#pragma unroll
+            for (int j = 0; j < CN; ++j) {
+                const int qx = gx - (j - CD);
+                const bool ok = inside && qy >= 0 && qy < H && qx >= 0 && qx < W;
+                wm |= (ok ? 1u : 0u) << j;
+                w[j] = dcorr[(ok ? ((size_t)(n * H + qy) * W + qx) * dcorr_ld : 0) + i * CN + j];
+            }
+        }
+    };
+
+    fetch(0);
     for (int ch0 = 0; ch0 < C; ch0 += CCH) {
         __syncthreads();
-        stage_halo(other, other_ld, C, n % other_images, H, W, ty * CT_H, tx * CT_W, ch0, xs);
+        commit();
         __syncthreads();
+        if (ch0 + CCH < C) fetch(ch0 + CCH);
         float4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wcur[CN], wnext[CN];
+        unsigned mcur = 0, mnext = 0;
+        load_row(0, wcur, mcur);
 #pragma unroll 1
         for (int i = 0; i < CN; ++i) {
-            float wgt[CN];
-            if (WHICH == 1) {
-#pragma unroll
-                for (int j = 0; j < CN; ++j) wgt[j] = inside ? dcorr[pix * dcorr_ld + i * CN + j] : 0.f;
-            } else {
-                const int qy = gy - (i - CD);
-#pragma unroll
-                for (int j = 0; j < CN; ++j) {
-                    const int qx = gx - (j - CD);
-                    float v = 0.f;
-                    if (inside && qy >= 0 && qy < H && qx >= 0 && qx < W)
-                        v = dcorr[((size_t)(n * H + qy) * W + qx) * dcorr_ld + i * CN + j];
-                    wgt[j] = v;
-                }
-            }
+            if (i + 1 < CN) load_row(i + 1, wnext, mnext);
             const int hy = WHICH == 1 ? py + i : py + 2 * CD - i;
 #pragma unroll
             for (int j = 0; j < CN; ++j) {
                 const int hx = WHICH == 1 ? px + j : px + 2 * CD - j;
                 const float* p = xs + (hy * CHW + hx) * CLD;
-                const float w = wgt[j];
+                const float w = (mcur >> j) & 1 ? wcur[j] : 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = ld4(p + 4 * q);
                     acc[q].x += w * b.x; acc[q].y += w * b.y; acc[q].z += w * b.z; acc[q].w += w * b.w;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < CN; ++j) wcur[j] = wnext[j];
+            mcur = mnext;
         }
         if (inside) {
 #pragma unroll
