@@ -34,6 +34,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels at element index `idx` of an fp32 or bf16 activation buffer
+__device__ __forceinline__ float4 ldx4(const float* base, size_t idx, int is_bf16) {
+    if (is_bf16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    return ld4(base + idx);
+}
+__device__ __forceinline__ void stx4(float* base, size_t idx, int is_bf16, float4 v) {
+    if (is_bf16)
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) =
+            (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    else
+        st4(base + idx, v);
+}
+
 // Sum over the lanes of a wave that share the same (lane / width) group, width = power of two <= 64.
 __device__ __forceinline__ float group_sum(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

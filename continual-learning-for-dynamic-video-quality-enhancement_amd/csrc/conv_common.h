@@ -4,25 +4,6 @@
 
 namespace nvq {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// 4 consecutive channels at element index `idx` of an fp32 or bf16 activation buffer
-__device__ __forceinline__ float4 ldx4(const float* base, size_t idx, int is_bf16) {
-    if (is_bf16) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
-        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-    }
-    return ld4(base + idx);
-}
-__device__ __forceinline__ void stx4(float* base, size_t idx, int is_bf16, float4 v) {
-    if (is_bf16)
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) =
-            (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    else
-        st4(base + idx, v);
-}
-
 constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in, int in_ld,
                                                      const float* __restrict__ weight, int C,
                                                      float* __restrict__ out, int out_ld, int H, int W,
-                                                     int flip, long total) {
+                                                     int flip, int in_bf16, int out_bf16, long total) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
     for (int i = threadIdx.x; i < 9 * C; i += 256) {
         const int c = i % C, tap = i / C;
@@ -156,18 +156,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ i
         for (int dx = 0; dx < 3; ++dx) {
             const int xx = x + dx - 1;
             if (xx < 0 || xx >= W) continue;
-            const float4 v = ld4(in + (pixlin + (long)(dy - 1) * W + (dx - 1)) * in_ld + 4 * c4);
+            const float4 v = ldx4(in, (size_t)(pixlin + (long)(dy - 1) * W + (dx - 1)) * in_ld + 4 * c4, in_bf16);
             const float4 w = ld4(wl + (dy * 3 + dx) * C + 4 * c4);
             acc.x += v.x * w.x; acc.y += v.y * w.y; acc.z += v.z * w.z; acc.w += v.w * w.w;
         }
     }
-    st4(out + pixlin * out_ld + 4 * c4, acc);
+    stx4(out, (size_t)pixlin * out_ld + 4 * c4, out_bf16, acc);
 }
 
 // part[blk][C*9]
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, int x_ld,
                                                            const float* __restrict__ dy, int dy_ld, int C,
-                                                           int H, int W, long npix,
+                                                           int H, int W, long npix, int x_bf16, int dy_bf16,
                                                            float* __restrict__ part) {
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
         const int xx0 = p % W;
         const int yy0 = (p / W) % H;
-        const float4 g = ld4(dy + p * dy_ld + 4 * c4);
+        const float4 g = ldx4(dy, (size_t)p * dy_ld + 4 * c4, dy_bf16);
 #pragma unroll
         for (int ddy = 0; ddy < 3; ++ddy) {
             const int yy = yy0 + ddy - 1;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
             for (int ddx = 0; ddx < 3; ++ddx) {
                 const int xx = xx0 + ddx - 1;
                 if (xx < 0 || xx >= W) continue;
-                const float4 v = ld4(x + (p + (long)(ddy - 1) * W + (ddx - 1)) * x_ld + 4 * c4);
+                const float4 v = ldx4(x, (size_t)(p + (long)(ddy - 1) * W + (ddx - 1)) * x_ld + 4 * c4, x_bf16);
                 float4& s = acc[ddy * 3 + ddx];
                 s.x += v.x * g.x; s.y += v.y * g.y; s.z += v.z * g.z; s.w += v.w * g.w;
             }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 // ---------------------------------------------------------------- BatchNorm
 // grid (blocks per group, G): part[g][blk][2C] = {sum, sum of squares}
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int x_ld, int C,
-                                                       long group_pix, float* __restrict__ part) {
+                                                       long group_pix, int x_bf16, float* __restrict__ part) {
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
     const int npl = 256 / C4;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const long base = (long)blockIdx.y * group_pix;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     for (long p = (long)blockIdx.x * npl + pl; p < group_pix; p += (long)gridDim.x * npl) {
-        const float4 v = ld4(x + (base + p) * x_ld + 4 * c4);
+        const float4 v = ldx4(x, (size_t)(base + p) * x_ld + 4 * c4, x_bf16);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
     }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, int res_ld, float* __restrict__ outA,
     int outA_ld, int outA_coff, int split_images, float* __restrict__ outB, int outB_ld, int outB_coff,
-    long total) {
+    int x_bf16, int out_bf16, long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
     const long pix = gid / C4;
     const int n = pix / img_pix;
     const int g = n / group_images;
-    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 v = ldx4(x, (size_t)pix * x_ld + 4 * c4, x_bf16);
     const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
     const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
     float4 y;
@@ -311,16 +311,17 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
         y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     }
     if (n < split_images)
-        st4(outA + pix * outA_ld + outA_coff + 4 * c4, y);
+        stx4(outA, (size_t)pix * outA_ld + outA_coff + 4 * c4, out_bf16, y);
     else
-        st4(outB + (pix - (long)split_images * img_pix) * outB_ld + outB_coff + 4 * c4, y);
+        stx4(outB, (size_t)(pix - (long)split_images * img_pix) * outB_ld + outB_coff + 4 * c4, out_bf16, y);
 }
 
 // backward pass 1: part[g][blk][2C] = {sum dyr, sum dyr*xhat}, dyr = dy * [bn(x) > 0]
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C,
     long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, int dy_bf16, int x_bf16,
+    float* __restrict__ part) {
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
     const int npl = 256 / C4;
@@ -332,8 +333,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     for (long p = (long)blockIdx.x * npl + pl; p < group_pix; p += (long)gridDim.x * npl) {
-        const float4 v = ld4(x + (base + p) * x_ld + 4 * c4);
-        float4 d = ld4(dy + (base + p) * dy_ld + 4 * c4);
+        const float4 v = ldx4(x, (size_t)(base + p) * x_ld + 4 * c4, x_bf16);
+        float4 d = ldx4(dy, (size_t)(base + p) * dy_ld + 4 * c4, dy_bf16);
         const float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z,
                     hw = (v.w - m.w) * is.w;
         if (!(hx * ga.x + be.x > 0.f)) d.x = 0.f;
@@ -383,15 +384,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C, long img_pix,
     int group_images, long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
-    int training, float* __restrict__ dx, int dx_ld, long total) {
+    int training, float* __restrict__ dx, int dx_ld, int dy_bf16, int x_bf16, int dx_bf16, long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
     const int c4 = gid % C4;
     const long pix = gid / C4;
     const int g = (pix / img_pix) / group_images;
-    const float4 v = ld4(x + pix * x_ld + 4 * c4);
-    const float4 d0 = ld4(dy + pix * dy_ld + 4 * c4);
+    const float4 v = ldx4(x, (size_t)pix * x_ld + 4 * c4, x_bf16);
+    const float4 d0 = ldx4(dy, (size_t)pix * dy_ld + 4 * c4, dy_bf16);
     const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
     const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const float d = (h * gv[e] + bv[e] > 0.f) ? dv[e] : 0.f;
         o[e] = training ? gv[e] * iv[e] * (d - a1[e] * inv_n - h * a2[e] * inv_n) : gv[e] * iv[e] * d;
     }
-    st4(dx + pix * dx_ld + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+    stx4(dx, (size_t)pix * dx_ld + 4 * c4, dx_bf16, make_float4(o[0], o[1], o[2], o[3]));
 }
 
 // ---------------------------------------------------------------- slice axpy
@@ -513,24 +514,24 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
 }
 
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, float* out, int out_ld,
-                       int N, int H, int W, int flip, void* stream) {
+                       int N, int H, int W, int flip, int in_bf16, int out_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
                 "dwconv_forward: C %d ld %d/%d", C, in_ld, out_ld);
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(dwconv_kernel, dim3(ceil_div(total, 256)), dim3(256), (size_t)9 * C * sizeof(float),
-                       (hipStream_t)stream, in, in_ld, weight, C, out, out_ld, H, W, flip, total);
+                       (hipStream_t)stream, in, in_ld, weight, C, out, out_ld, H, W, flip, in_bf16, out_bf16, total);
     return check_launch("dwconv_forward");
 }
 
 int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C, int N, int H, int W,
                      float* dweight, float* workspace, size_t workspace_bytes, int accumulate,
-                     void* stream) {
+                     int x_bf16, int dy_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "dwconv_wgrad: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0, "dwconv_wgrad: ld");
     const long npix = (long)N * H * W;
     const int nblk = blocks_for(npix, C);
     if ((size_t)nblk * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy, dy_ld, C, H, W, npix, workspace);
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy, dy_ld, C, H, W, npix, x_bf16, dy_bf16, workspace);
     int rc = check_launch("dwconv_wgrad");
     if (rc) return rc;
     return launch_reduce_partials(workspace, nblk, C * 9, 1.f, dweight, accumulate, (hipStream_t)stream);
@@ -538,7 +539,7 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
 
 int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H, int W, float eps,
                  float momentum, const int* order_host, float* mean, float* invstd, float* running_mean,
-                 float* running_var, float* workspace, size_t workspace_bytes, void* stream) {
+                 float* running_var, float* workspace, size_t workspace_bytes, int x_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "bn_stats: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(group_images > 0 && N % group_images == 0 && N / group_images <= NVQ_MAX_T, "bn_stats: groups");
     NVQ_REQUIRE(x_ld % 4 == 0 && aligned16(x), "bn_stats: ld");
@@ -547,7 +548,7 @@ int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H
     const int nblk = blocks_for(group_pix, C);
     if ((size_t)G * nblk * 2 * C * sizeof(float) > workspace_bytes) { set_error("bn_stats: workspace"); return NVQ_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, G), dim3(256), 0, s, x, x_ld, C, group_pix, workspace);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, G), dim3(256), 0, s, x, x_ld, C, group_pix, x_bf16, workspace);
     int rc = check_launch("bn_stats");
     if (rc) return rc;
     GroupOrder order;
@@ -567,7 +568,8 @@ int nvq_bn_eval_stats(const float* running_mean, const float* running_var, int C
 int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, int H, int W,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res, int res_ld, float* outA, int outA_ld, int outA_coff,
-                      int split_images, float* outB, int outB_ld, int outB_coff, void* stream) {
+                      int split_images, float* outB, int outB_ld, int outB_coff, int x_bf16, int out_bf16,
+                      void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && outA_ld % 4 == 0 && outA_coff % 4 == 0 && outB_ld % 4 == 0 &&
                     outB_coff % 4 == 0 && (!res || res_ld % 4 == 0),
                 "bn_apply_relu: alignment");
@@ -575,7 +577,7 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
                        C, (long)H * W, group_images, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld,
-                       outA_coff, split_images, outB, outB_ld, outB_coff, total);
+                       outA_coff, split_images, outB, outB_ld, outB_coff, x_bf16, out_bf16, total);
     return check_launch("bn_apply_relu");
 }
 
@@ -583,7 +585,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
                          int group_images, int H, int W, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int training, float* dx, int dx_ld,
                          float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
-                         int accumulate, void* stream) {
+                         int accumulate, int dy_bf16, int x_bf16, int dx_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "bn_relu_backward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(dy_ld % 4 == 0 && x_ld % 4 == 0 && dx_ld % 4 == 0, "bn_relu_backward: ld");
     NVQ_REQUIRE(group_images > 0 && N % group_images == 0 && N / group_images <= NVQ_MAX_T, "bn_relu_backward: groups");
@@ -595,7 +597,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
     float* sums = workspace + part_floats;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, G), dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, mean,
-                       invstd, gamma, beta, workspace);
+                       invstd, gamma, beta, dy_bf16, x_bf16, workspace);
     int rc = check_launch("bn_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, sums,
@@ -605,7 +607,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dy, dy_ld, x, x_ld, C,
                        (long)H * W, group_images, group_pix, mean, invstd, gamma, beta, sums, training, dx, dx_ld,
-                       total);
+                       dy_bf16, x_bf16, dx_bf16, total);
     return check_launch("bn_bwd_apply");
 }
 

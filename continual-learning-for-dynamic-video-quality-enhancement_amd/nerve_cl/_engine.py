@@ -92,9 +92,9 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     cur = feat0
     for k in range(3):
         pre = f"feature_extractor.body.{k}."
-        d = _new(dev, NI, H, W, F)
+        d = _new(dev, NI, H, W, F, dtype=act_dtype)
         K.dwconv_forward(cur, P[pre + "depthwise.weight"], d)
-        p = _new(dev, NI, H, W, F)
+        p = _new(dev, NI, H, W, F, dtype=act_dtype)
         wp = K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math)
         K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
         mean, invstd = _new(dev, T, F), _new(dev, T, F)
@@ -105,7 +105,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         else:
             K.bn_eval_stats(P[pre + "bn.running_mean"], P[pre + "bn.running_var"], T, mean, invstd, BN_EPS)
         if k < 2:
-            r = _new(dev, NI, H, W, F)
+            r = _new(dev, NI, H, W, F, dtype=act_dtype)
             K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], None, Sl(r), NI)
         else:
             # features = relu(bn(.)) + head features; centre frame lands in its slot of `aligned`
@@ -327,15 +327,15 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dcur = dfeat_all
     for k in (2, 1, 0):
         pre = f"feature_extractor.body.{k}."
-        dp = _new(dev, NI, H, W, F)
+        dp = _new(dev, NI, H, W, F, dtype=act_dtype)
         K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
                            P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
         _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
-        dd = _new(dev, NI, H, W, F)
+        dd = _new(dev, NI, H, W, F, dtype=act_dtype)
         K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin = sv.feat0 if k == 0 else sv.acts[k - 1]
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws)
-        dx = _new(dev, NI, H, W, F)
+        dx = _new(dev, NI, H, W, F, dtype=act_dtype if k > 0 else torch.float32)
         K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
         dcur = dx
     K.axpy_slice(Sl(dcur), Sl(dfeat_all))     # + the skip  feat = body(h) + h

@@ -74,12 +74,12 @@ SIGNATURES = {
     "nvq_sizeof_wgrad_desc": (sz, []),
     "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, vp]),
-    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
-    "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]),
-    "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
+    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp]),
+    "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, ci, vp]),
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
-    "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, vp]),
-    "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
@@ -138,6 +138,10 @@ def require_device(t: torch.Tensor, what: str = "tensor") -> None:
         raise RuntimeError(
             f"{what} lives on {t.device}: the nerve_cl super-resolution path runs only as HIP kernels "
             "on an AMD GPU (move the model and its inputs to 'cuda'); there is no CPU fallback.")
+
+
+def is_bf16(t: Optional[torch.Tensor]) -> int:
+    return int(t is not None and t.dtype == torch.bfloat16)
 
 
 def ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
@@ -348,14 +352,14 @@ def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False):
     N, H, W, ld = x.shape
     Cc = weight.shape[0]
     check(lib().nvq_dwconv_forward(ptr(x), ld, ptr(weight), Cc, ptr(out), out.shape[-1], N, H, W, int(flip),
-                                   stream()), "nvq_dwconv_forward")
+                                   is_bf16(x), is_bf16(out), stream()), "nvq_dwconv_forward")
 
 
 def dwconv_wgrad(x: torch.Tensor, dy: torch.Tensor, dweight, ws, accumulate=False):
     N, H, W, ld = x.shape
     Cc = dweight.shape[0]
     check(lib().nvq_dwconv_wgrad(ptr(x), ld, ptr(dy), dy.shape[-1], Cc, N, H, W, ptr(dweight), ptr(ws),
-                                 ws.numel() * 4, int(accumulate), stream()), "nvq_dwconv_wgrad")
+                                 ws.numel() * 4, int(accumulate), is_bf16(x), is_bf16(dy), stream()), "nvq_dwconv_wgrad")
 
 
 def bn_stats(x: torch.Tensor, group_images: int, order: Sequence[int], mean, invstd, rmean, rvar, ws,
@@ -363,7 +367,7 @@ def bn_stats(x: torch.Tensor, group_images: int, order: Sequence[int], mean, inv
     N, H, W, ld = x.shape
     Cc = mean.shape[-1]
     check(lib().nvq_bn_stats(ptr(x), ld, Cc, N, group_images, H, W, eps, momentum, int_array(order), ptr(mean),
-                             ptr(invstd), ptr(rmean), ptr(rvar), ptr(ws), ws.numel() * 4, stream()),
+                             ptr(invstd), ptr(rmean), ptr(rvar), ptr(ws), ws.numel() * 4, is_bf16(x), stream()),
           "nvq_bn_stats")
 
 
@@ -379,7 +383,7 @@ def bn_apply_relu(x: torch.Tensor, group_images: int, mean, invstd, gamma, beta,
     check(lib().nvq_bn_apply_relu(ptr(x), ld, Cc, N, group_images, H, W, ptr(mean), ptr(invstd), ptr(gamma),
                                   ptr(beta), ptr(res), res.shape[-1] if res is not None else 0, ptr(outA.t),
                                   outA.ld, outA.coff, split_images, ptr(outB.t) if outB else None,
-                                  outB.ld if outB else 0, outB.coff if outB else 0, stream()),
+                                  outB.ld if outB else 0, outB.coff if outB else 0, is_bf16(x), outA.bf16, stream()),
           "nvq_bn_apply_relu")
 
 
@@ -389,7 +393,8 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
     Cc = gamma.numel()
     check(lib().nvq_bn_relu_backward(ptr(dy), dy.shape[-1], ptr(x), ld, Cc, N, group_images, H, W, ptr(mean),
                                      ptr(invstd), ptr(gamma), ptr(beta), int(training), ptr(dx), dx.shape[-1],
-                                     ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), stream()),
+                                     ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), is_bf16(dy),
+                                     is_bf16(x), is_bf16(dx), stream()),
           "nvq_bn_relu_backward")
 
 

@@ -136,12 +136,14 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
                    int accumulate, void* stream);
 
 /* Depthwise 3x3 (groups = C, no bias), efficient_layers.py:38-46.  weight [C][1][3][3].
- * flip == 1 gives the input gradient. */
+ * flip == 1 gives the input gradient.  The *_bf16 flags of this section give the storage type of the
+ * corresponding activation tensor (0 = fp32, 1 = bf16; arithmetic and statistics stay fp32). */
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C,
-                       float* out, int out_ld, int N, int H, int W, int flip, void* stream);
+                       float* out, int out_ld, int N, int H, int W, int flip,
+                       int in_bf16, int out_bf16, void* stream);
 int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C,
                      int N, int H, int W, float* dweight, float* workspace,
-                     size_t workspace_bytes, int accumulate, void* stream);
+                     size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16, void* stream);
 
 /* BatchNorm2d, efficient_layers.py:59,65.  The N images form G = N/group_images groups
  * (one per feature-extractor call); statistics are per (group, channel) over
@@ -153,7 +155,7 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
 int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H, int W,
                  float eps, float momentum, const int* order_host,
                  float* mean, float* invstd, float* running_mean, float* running_var,
-                 float* workspace, size_t workspace_bytes, void* stream);
+                 float* workspace, size_t workspace_bytes, int x_bf16, void* stream);
 /* Evaluation: fill mean/invstd [G][C] from the running statistics. */
 int nvq_bn_eval_stats(const float* running_mean, const float* running_var, int C, int G,
                       float eps, float* mean, float* invstd, void* stream);
@@ -164,7 +166,7 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
                       const float* mean, const float* invstd, const float* gamma,
                       const float* beta, const float* res, int res_ld,
                       float* outA, int outA_ld, int outA_coff, int split_images,
-                      float* outB, int outB_ld, int outB_coff, void* stream);
+                      float* outB, int outB_ld, int outB_coff, int x_bf16, int out_bf16, void* stream);
 /* Backward of y = relu(bn(x)).  dy is the gradient w.r.t. y; the ReLU mask is recomputed
  * from x and the statistics (gamma*(x-mean)*invstd + beta > 0), so y itself is not needed.
  * training != 0: batch-statistics backward; else running-statistics backward.
@@ -174,7 +176,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
                          const float* gamma, const float* beta, int training,
                          float* dx, int dx_ld, float* dgamma, float* dbeta,
                          float* workspace, size_t workspace_bytes, int accumulate,
-                         void* stream);
+                         int dy_bf16, int x_bf16, int dx_bf16, void* stream);
 
 /* ------------------------------------------------------------------ motion
  * LiteFlowNetCorrelation(d=4).forward, efficient_layers.py:313-343.

@@ -562,3 +562,40 @@ def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     K.conv_wgrad(K.Sl(xs), cin, K.Sl(ds, cout, 8), dw, db, ws_tensor(K), k, math=K.MATH_BF16)
     assert rel(dw, w.grad) < TOL
     assert rel(db, dy.sum((0, 2, 3))) < TOL
+
+
+def test_extractor_kernels_with_bf16_stored_tensors(K):
+    """Depthwise conv and BatchNorm kernels reading / writing bf16-stored tensors (fp32 arithmetic inside)."""
+    C, B, G, H, W = 32, 2, 3, 9, 14
+    N = B * G
+    x = bf(rnd(N, C, H, W) * 1.5 + 0.3)
+    w = rnd(C, 1, 3, 3)
+    ref = F.conv2d(x, w, None, padding=1, groups=C)
+    out = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.dwconv_forward(to_nhwc_bf16(x), w.cuda(), out)
+    assert rel(out.float().permute(0, 3, 1, 2), ref) < 5e-3            # one bf16 rounding of the result
+    dy = bf(rnd(N, C, H, W, seed=6))
+    wg = w.clone().requires_grad_()
+    F.conv2d(x, wg, None, padding=1, groups=C).backward(dy)
+    dw = torch.empty(C, 1, 3, 3, device="cuda")
+    K.dwconv_wgrad(to_nhwc_bf16(x), to_nhwc_bf16(dy), dw, ws_tensor(K))
+    assert rel(dw, wg.grad) < TOL
+    # BatchNorm (training statistics) on a bf16 tensor, bf16 output, bf16 gradient in/out
+    xg = x.clone().requires_grad_()
+    gamma, beta = (1 + 0.2 * rnd(C)).requires_grad_(), (0.1 * rnd(C, seed=2)).requires_grad_()
+    ys = [F.relu(F.batch_norm(xg[g * B:(g + 1) * B], None, None, gamma, beta, True, 0.1, 1e-5)) for g in range(G)]
+    y = torch.cat(ys, 0)
+    y.backward(dy)
+    xb = to_nhwc_bf16(x)
+    mean, invstd = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+    ws = ws_tensor(K)
+    K.bn_stats(xb, B, list(range(G)), mean, invstd, None, None, ws)
+    yb = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.bn_apply_relu(xb, B, mean, invstd, gamma.detach().cuda(), beta.detach().cuda(), None, K.Sl(yb), N)
+    assert rel(yb.float().permute(0, 3, 1, 2), y.detach()) < 5e-3
+    dx = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    K.bn_relu_backward(to_nhwc_bf16(dy), xb, B, mean, invstd, gamma.detach().cuda(), beta.detach().cuda(), True, dx, dg,
+                       db, ws)
+    assert rel(dx.float().permute(0, 3, 1, 2), xg.grad) < 8e-3
+    assert rel(dg, gamma.grad) < 5e-5 and rel(db, beta.grad) < 5e-5
