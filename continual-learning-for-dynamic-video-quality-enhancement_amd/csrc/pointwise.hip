@@ -207,6 +207,154 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------- depthwise 3x3, LDS-tiled (C % 32 == 0)
+// Workgroup = 8x32-pixel tile x 32 channels.  The halo tile sits in LDS as fp32 [340 px][32 ch]; thread
+// (c4 = tid & 7, x = tid >> 3) walks its column down the 8 rows with a 3-row window, so every input value is
+// read from LDS ~1.25 times instead of 9 global loads per output (the untiled kernel is bound by load
+// instructions, not bytes: halving the bytes with bf16 storage did not change its time).
+constexpr int DT_H = 8, DT_W = 32, DT_C = 32;
+constexpr int DT_HW = DT_W + 2, DT_HH = DT_H + 2, DT_NPIX = DT_HW * DT_HH;
+
+__device__ __forceinline__ void dw_stage_halo(const float* __restrict__ in, int in_ld, int in_bf16, int n, int H, int W,
+                                              int ty0, int tx0, int ch0, float* xs) {
+    if (in_bf16) {
+        for (int item = threadIdx.x; item < DT_NPIX * 4; item += 256) {      // 8 bf16 channels per piece
+            const int hp = item >> 2, q = item & 3;
+            const int hy = hp / DT_HW, hx = hp - hy * DT_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t idx = ((size_t)(n * H + gy) * W + gx) * in_ld + ch0 + 8 * q;
+                a = ldx4(in, idx, 1);
+                b = ldx4(in, idx + 4, 1);
+            }
+            st4(xs + hp * DT_C + 8 * q, a);
+            st4(xs + hp * DT_C + 8 * q + 4, b);
+        }
+    } else {
+        for (int item = threadIdx.x; item < DT_NPIX * 8; item += 256) {
+            const int hp = item >> 3, q = item & 7;
+            const int hy = hp / DT_HW, hx = hp - hy * DT_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                a = ld4(in + ((size_t)(n * H + gy) * W + gx) * in_ld + ch0 + 4 * q);
+            st4(xs + hp * DT_C + 4 * q, a);
+        }
+    }
+}
+
+// grid (tiles, C/32)
+__global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restrict__ in, int in_ld,
+                                                           const float* __restrict__ weight, int C,
+                                                           float* __restrict__ out, int out_ld, int H, int W,
+                                                           int tilesX, int tilesY, int flip, int in_bf16, int out_bf16) {
+    __shared__ __attribute__((aligned(16))) float xs[DT_NPIX * DT_C];
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int ch0 = blockIdx.y * DT_C;
+    const int c4 = threadIdx.x & 7, x = threadIdx.x >> 3;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        const int c = ch0 + 4 * c4;
+        w[t] = make_float4(weight[(c + 0) * 9 + tt], weight[(c + 1) * 9 + tt], weight[(c + 2) * 9 + tt], weight[(c + 3) * 9 + tt]);
+    }
+    dw_stage_halo(in, in_ld, in_bf16, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+    __syncthreads();
+    const int gx = tx * DT_W + x;
+    float4 r[3][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) r[a][b] = ld4(xs + (a * DT_HW + x + b) * DT_C + 4 * c4);
+#pragma unroll
+    for (int y = 0; y < DT_H; ++y) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) r[2][b] = ld4(xs + ((y + 2) * DT_HW + x + b) * DT_C + 4 * c4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float4 v = r[a][b], ww = w[a * 3 + b];
+                acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
+            }
+        const int gy = ty * DT_H + y;
+        if (gy < H && gx < W) stx4(out, ((size_t)(n * H + gy) * W + gx) * out_ld + ch0 + 4 * c4, out_bf16, acc);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+    }
+}
+
+// grid (<= 512 persistent blocks over tiles, C/32): part[blockIdx.x][C*9]
+__global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(const float* __restrict__ x, int x_ld,
+                                                                 const float* __restrict__ dy, int dy_ld, int C, int H,
+                                                                 int W, int tilesX, int tilesY, int ntiles, int x_bf16,
+                                                                 int dy_bf16, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float xs[DT_NPIX * DT_C];
+    const int ch0 = blockIdx.y * DT_C;
+    const int c4 = threadIdx.x & 7, xx = threadIdx.x >> 3;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bt = tile;
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
+        __syncthreads();
+        dw_stage_halo(x, x_ld, x_bf16, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+        __syncthreads();
+        const int gx = tx * DT_W + xx;
+        float4 r[3][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[a][b] = ld4(xs + (a * DT_HW + xx + b) * DT_C + 4 * c4);
+#pragma unroll
+        for (int y = 0; y < DT_H; ++y) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[2][b] = ld4(xs + ((y + 2) * DT_HW + xx + b) * DT_C + 4 * c4);
+            const int gy = ty * DT_H + y;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W) g = ldx4(dy, ((size_t)(n * H + gy) * W + gx) * dy_ld + ch0 + 4 * c4, dy_bf16);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float4 v = r[a][b];
+                    float4& s = acc[a * 3 + b];
+                    s.x += v.x * g.x; s.y += v.y * g.y; s.z += v.z * g.z; s.w += v.w * g.w;
+                }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+        }
+    }
+    // reduce over the 32 x-lanes that share c4 (threads c4 + 8k), through LDS
+    float4* buf = reinterpret_cast<float4*>(xs);
+    float* prow = part + (size_t)blockIdx.x * C * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        buf[threadIdx.x] = acc[t];
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 32; ++k) {
+                const float4 v = buf[threadIdx.x + 8 * k];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const int c = ch0 + 4 * threadIdx.x;
+            prow[(c + 0) * 9 + t] = s.x; prow[(c + 1) * 9 + t] = s.y;
+            prow[(c + 2) * 9 + t] = s.z; prow[(c + 3) * 9 + t] = s.w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- BatchNorm
 // grid (blocks per group, G): part[g][blk][2C] = {sum, sum of squares}
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int x_ld, int C,
@@ -491,7 +639,7 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     const long npix = (long)nslots * B * H * W;
     const int K = Cin * 9;
     int nblk = blocks_for(npix, F);
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;       // 4 workgroups per CU: the 112 accumulators per thread need the latency cover
     const size_t row = (size_t)F * K + F;
     if (row * nblk * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
@@ -517,6 +665,13 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
                        int N, int H, int W, int flip, int in_bf16, int out_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
                 "dwconv_forward: C %d ld %d/%d", C, in_ld, out_ld);
+    if (C % DT_C == 0) {
+        const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
+        hipLaunchKernelGGL(dwconv_tiled_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DT_C), dim3(256), 0,
+                           (hipStream_t)stream, in, in_ld, weight, C, out, out_ld, H, W, tilesX, tilesY, flip, in_bf16,
+                           out_bf16);
+        return check_launch("dwconv_tiled");
+    }
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(dwconv_kernel, dim3(ceil_div(total, 256)), dim3(256), (size_t)9 * C * sizeof(float),
                        (hipStream_t)stream, in, in_ld, weight, C, out, out_ld, H, W, flip, in_bf16, out_bf16, total);
@@ -529,6 +684,17 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
     NVQ_REQUIRE(pow2_c4(C), "dwconv_wgrad: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0, "dwconv_wgrad: ld");
     const long npix = (long)N * H * W;
+    if (C % DT_C == 0) {
+        const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
+        const int ntiles = tilesX * tilesY * N;
+        const int nb = ntiles < 512 ? ntiles : 512;
+        if ((size_t)nb * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
+        hipLaunchKernelGGL(dwconv_wgrad_tiled_kernel, dim3(nb, C / DT_C), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy,
+                           dy_ld, C, H, W, tilesX, tilesY, ntiles, x_bf16, dy_bf16, workspace);
+        int rc0 = check_launch("dwconv_wgrad_tiled");
+        if (rc0) return rc0;
+        return launch_reduce_partials(workspace, nb, C * 9, 1.f, dweight, accumulate, (hipStream_t)stream);
+    }
     const int nblk = blocks_for(npix, C);
     if ((size_t)nblk * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
     hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, x_ld, dy, dy_ld, C, H, W, npix, x_bf16, dy_bf16, workspace);
