@@ -16,8 +16,8 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 N, H, W = 2, 540, 960
-for cin, cout, k, dt in ((192, 32, 3, torch.bfloat16), (192, 32, 3, torch.float32), (224, 64, 3, torch.bfloat16), (64, 32, 3, torch.bfloat16),
-                         (224, 64, 1, torch.bfloat16)):
+for cin, cout, k, dt in ((192, 32, 3, torch.bfloat16), (128, 32, 3, torch.bfloat16), (64, 32, 3, torch.bfloat16),
+                         (192, 32, 3, torch.float32), (224, 64, 3, torch.bfloat16), (224, 64, 1, torch.bfloat16)):
     x = torch.randn(N, H, W, 224, device="cuda").to(dt)
     out = torch.empty(N, H, W, 224, device="cuda", dtype=dt)
     w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
