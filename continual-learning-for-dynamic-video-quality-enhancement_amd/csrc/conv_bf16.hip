@@ -198,30 +198,35 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
 }
 
 // ---------------------------------------------------------------- weight gradient
-// Same decomposition as the fp32 kernel (grid = pixel split x 32-ci chunk x 32-co chunk, wave = one 16x16
-// block of (ci, co) for all taps) with K = the 32 pixels of one tile row per MFMA.  The LDS images stay
-// [pixel][32 ch] (96-B pixels); ds_read_b64_tr_b16 delivers, per 16-lane group, 4 pixels x 16 channels
-// transposed, i.e. exactly the k-major operand the MFMA wants.  k order inside a row: group g, element e
-// -> x = 4g + e (e < 4), 16 + 4g + e - 4 (e >= 4), identical for both operands, so that the two 16-lane
-// groups of a 32-lane half read 8 consecutive pixels = 8 distinct 32-B bank ranges.
+// grid = (pixel split, ci chunk, 32-co chunk); K = the 32 pixels of one tile row per MFMA.  The LDS images stay
+// [pixel][channels]; ds_read_b64_tr_b16 delivers, per 16-lane group, 4 pixels x 16 channels transposed, i.e.
+// exactly the k-major operand the MFMA wants.  k order inside a row: group g, element e -> x = 4g + e (e < 4),
+// 16 + 4g + e - 4 (e >= 4), identical for both operands, so that the two 16-lane groups of a 32-lane half read 8
+// consecutive pixels = 8 distinct 32-B bank ranges (pixel stride 96 B, or 160 B for the 64-channel image).
 // XB / YB: x / dy are stored as bf16.  Staging pieces are 16 bytes: 4 fp32 or 8 bf16 channels.
-template <int KS, bool XB, bool YB>
+// CIC: input channels per workgroup.  32: wave = one 16x16 (ci, co) block for all taps.  64 (bf16 x only): wave =
+// one 16-ci block x both 16-co blocks, i.e. twice the MFMA work per staged dy tile and dy re-read half as often -
+// the per-tile iteration is latency-bound, so doing more per iteration is what pays.
+template <int KS, bool XB, bool YB, int CIC>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc d, int tilesX, int tilesY,
-                                                             int ntiles, int nci, int nco) {
+                                                             int ntiles, int nci32, int nco) {
+    static_assert(CIC == 32 || (CIC == 64 && XB), "64-channel chunks need bf16 x");
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int HW_ = TW + 2 * HALO;
     constexpr int HH_ = TH + 2 * HALO;
     constexpr int NPIX = HW_ * HH_;
-    constexpr int XPP = XB ? 4 : 8;                  // 16-byte pieces per pixel of the 32-channel X chunk
+    constexpr int XSX = CIC == 64 ? 80 : XSB;        // bf16 per staged x pixel (160 B / 96 B)
+    constexpr int XPP = (XB ? 4 : 8) * (CIC / 32);   // 16-byte pieces per pixel of the X chunk
     constexpr int YPP = YB ? 4 : 8;
-    constexpr int XCH = 32 / XPP, YCH = 32 / YPP;    // channels per piece
+    constexpr int XCH = CIC / XPP, YCH = 32 / YPP;   // channels per piece
     constexpr int XITEMS = NPIX * XPP;
     constexpr int XPER = (XITEMS + 255) / 256;
     constexpr int YPER = TH * TW * YPP / 256;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[(NPIX + TH * TW) * XSB];
+    constexpr int NCO = CIC == 64 ? 2 : 1;           // co blocks per wave
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSX + TH * TW * XSB];
     __bf16* xs = lds;
-    __bf16* dys = lds + NPIX * XSB;
+    __bf16* dys = lds + NPIX * XSX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -229,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     const int r = lane & 15;
     const int g = lane >> 4;
     const int q = r >> 2, p = r & 3;                 // tr-read role of this lane inside its 16-lane group
-    const int cib = wave >> 1, cob = wave & 1;
+    const int cib = CIC == 64 ? wave : wave >> 1;    // 16-ci block of this wave inside the chunk
+    const int cob0 = CIC == 64 ? 0 : (wave & 1);
     const int cic = blockIdx.y, coc = blockIdx.z;
     const int H = d.h, W = d.w;
     const float* x32 = d.x + d.x_coff;
@@ -237,16 +243,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     const float* dy32 = d.dy + d.dy_coff;
     const __bf16* dy16 = reinterpret_cast<const __bf16*>(d.dy) + d.dy_coff;
 
-    f32x4 acc[TAPS];
+    f32x4 acc[NCO][TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < NCO; ++a)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     u32x4 xr[XPER], yr[YPER];
     // fp32 column sums of dy (bias gradient): channels yq..yq+3 in bsumA, yq+4..yq+7 in bsumB (bf16 pieces only)
     float4 bsumA = make_float4(0.f, 0.f, 0.f, 0.f), bsumB = bsumA;
     const int xq = XCH * (tid & (XPP - 1));          // channel offset of this thread's X pieces inside the chunk
     const int yq = YCH * (tid & (YPP - 1));
-    const bool xch_ok = cic * WG_C + xq < d.cin;
+    const bool xch_ok = cic * CIC + xq < d.cin;
     const int ych = coc * WG_C + yq;
     const bool ych_ok = ych < d.cout;
     // all loads unconditional (invalid pieces read element 0 of the slice); the validity masks are applied in
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
             const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch_ok;
             xmask |= (ok ? 1u : 0u) << k;
-            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * WG_C + xq : 0;
+            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * CIC + xq : 0;
             if constexpr (XB) xr[k] = *reinterpret_cast<const u32x4*>(x16 + off);
             else xr[k] = *reinterpret_cast<const u32x4*>(x32 + off);
         }
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             const int item = tid + k * 256;
             if (item < XITEMS) {
                 const u32x4 v = (xmask >> k) & 1 ? xr[k] : z;
-                __bf16* dst = xs + (item / XPP) * XSB + XCH * (item & (XPP - 1));
+                __bf16* dst = xs + (item / XPP) * XSX + XCH * (item & (XPP - 1));
                 if constexpr (XB) *reinterpret_cast<u32x4*>(dst) = v;
                 else *reinterpret_cast<bf16x4*>(dst) = cvt4(as_f4(v));
             }
@@ -314,10 +322,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
         }
     };
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-    auto tr_read = [&](const __bf16* base, int pix, int chblock) -> s16x4 {
+    auto tr_read = [&](const __bf16* base, int stride, int pix, int chblock) -> s16x4 {
         // lane (q, p) supplies row `pix + q`'s address, columns 4p..4p+3 of the 16-channel block
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4_ptr)(base + (pix + q) * XSB + chblock * 16 + 4 * p));
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + (pix + q) * stride + chblock * 16 + 4 * p));
     };
 
     int tile = blockIdx.x;
@@ -329,27 +336,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 2
         for (int py = 0; py < TH; ++py) {
-            const s16x4 b0 = tr_read(dys, py * TW + 4 * g, cob);
-            const s16x4 b1 = tr_read(dys, py * TW + 16 + 4 * g, cob);
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 bfrag[NCO];
+#pragma unroll
+            for (int a = 0; a < NCO; ++a) {
+                const s16x4 b0 = tr_read(dys, XSB, py * TW + 4 * g, cob0 + a);
+                const s16x4 b1 = tr_read(dys, XSB, py * TW + 16 + 4 * g, cob0 + a);
+                bfrag[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int ddy = tap / KS, ddx = tap - ddy * KS;
                 const int hp = (py + ddy) * HW_ + ddx;
-                const s16x4 a0 = tr_read(xs, hp + 4 * g, cib);
-                const s16x4 a1 = tr_read(xs, hp + 16 + 4 * g, cib);
+                const s16x4 a0 = tr_read(xs, XSX, hp + 4 * g, cib);
+                const s16x4 a1 = tr_read(xs, XSX, hp + 16 + 4 * g, cib);
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[tap], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < NCO; ++a)
+                    acc[a][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[a], acc[a][tap], 0, 0, 0);
             }
         }
     }
 
-    float* part = d.workspace + ((size_t)(blockIdx.x * nci + cic) * nco + coc) * (TAPS * WG_C * WG_C);
+    // partial slabs are indexed in 32-ci units so the reduce kernel is independent of CIC
+    const int slab = cic * (CIC / 32) + (cib * 16) / 32;
+    if (slab < nci32) {                                      // wave-uniform
+        float* part = d.workspace + ((size_t)(blockIdx.x * nci32 + slab) * nco + coc) * (TAPS * WG_C * WG_C);
+        const int cil0 = (cib * 16) % 32;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+        for (int a = 0; a < NCO; ++a)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            part[(tap * WG_C + cib * 16 + 4 * g + e) * WG_C + cob * 16 + r] = acc[tap][e];
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    part[(tap * WG_C + cil0 + 4 * g + e) * WG_C + (cob0 + a) * 16 + r] = acc[a][tap][e];
+    }
 
     // bias partials: thread t's sums cover channels yq..yq+YCH-1 of the co chunk, pieces repeat every YPP threads
     if (cic == 0 && d.dbias != nullptr) {                    // uniform per workgroup
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             const int piece = tid / YCH, e = tid % YCH;      // channel `tid` of the chunk
             float s = 0.f;
             for (int k = 0; k < 256 / YPP; ++k) s += scratch[8 * (YPP * k + piece) + e];
-            float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+            float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
             bp[((size_t)blockIdx.x * nco + coc) * WG_C + tid] = s;
         }
     }
@@ -416,22 +436,32 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
 
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s) {
-    const dim3 grid(nsplit, nci, nco);
-#define NVQ_LAUNCH_WG(KS, XB, YB) \
-    hipLaunchKernelGGL((wgrad_bf16_kernel<KS, XB, YB>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco)
+    // nsplit / nci come from the caller in 32-ci units; with bf16 x and >= 64 input channels use 64-ci workgroups
+    const bool wide = d.x_bf16 && d.dy_bf16 && d.cin_w >= 64;   // (the bf16-x / fp32-dy wide variant spills)
+    const int ncig = wide ? (nci + 1) / 2 : nci;
+    if (wide) {
+        nsplit = WGRAD_MAX_WG / (ncig * nco);
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > ntiles) nsplit = ntiles;
+    }
+    const dim3 grid(nsplit, ncig, nco);
+#define NVQ_LAUNCH_WG(KS, XB, YB, CIC) \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<KS, XB, YB, CIC>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco)
     if (d.ksize == 3) {
-        if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(3, true, true);
-        else if (d.x_bf16) NVQ_LAUNCH_WG(3, true, false);
-        else if (d.dy_bf16) NVQ_LAUNCH_WG(3, false, true);
-        else NVQ_LAUNCH_WG(3, false, false);
+        if (wide) NVQ_LAUNCH_WG(3, true, true, 64);
+        else if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(3, true, true, 32);
+        else if (d.x_bf16) NVQ_LAUNCH_WG(3, true, false, 32);
+        else if (d.dy_bf16) NVQ_LAUNCH_WG(3, false, true, 32);
+        else NVQ_LAUNCH_WG(3, false, false, 32);
     } else {
-        if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(1, true, true);
-        else if (d.x_bf16) NVQ_LAUNCH_WG(1, true, false);
-        else if (d.dy_bf16) NVQ_LAUNCH_WG(1, false, true);
-        else NVQ_LAUNCH_WG(1, false, false);
+        if (wide) NVQ_LAUNCH_WG(1, true, true, 64);
+        else if (d.x_bf16 && d.dy_bf16) NVQ_LAUNCH_WG(1, true, true, 32);
+        else if (d.x_bf16) NVQ_LAUNCH_WG(1, true, false, 32);
+        else if (d.dy_bf16) NVQ_LAUNCH_WG(1, false, true, 32);
+        else NVQ_LAUNCH_WG(1, false, false, 32);
     }
 #undef NVQ_LAUNCH_WG
-    return check_launch("conv_wgrad_bf16");
+    return nsplit;      // > 0: the number of pixel splits actually used (the reduce kernel needs it)
 }
 
 }  // namespace nvq

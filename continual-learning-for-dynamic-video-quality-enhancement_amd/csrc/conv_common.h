@@ -7,7 +7,8 @@ namespace nvq {
 constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
-constexpr int WGRAD_MAX_WG = 512;
+constexpr int WGRAD_MAX_WG = 512;      // workgroups per wgrad launch (2 per CU)
+constexpr int WGRAD_MAX_SLABS = 1024;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds
 
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ void wgrad_bias_partial(const nvq_wgrad_desc& d, floa
         const int q = threadIdx.x >> 2, e = threadIdx.x & 3;   // channel 4q+e of the chunk
         float s = 0.f;
         for (int k = 0; k < 32; ++k) s += lds[4 * (8 * k + q) + e];
-        float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+        float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
         bp[((size_t)blockIdx.x * nco + coc) * WG_C + threadIdx.x] = s;
     }
 }

@@ -471,7 +471,7 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
 }
 
 size_t nvq_wgrad_workspace_bytes(void) {
-    return (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C * sizeof(float) + (size_t)512 * 256 * sizeof(float);
+    return (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C * sizeof(float) + (size_t)512 * 256 * sizeof(float);
 }
 
 int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
@@ -502,7 +502,9 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     const dim3 grid(nsplit, nci, nco);
     int rc;
     if (d.math == NVQ_MATH_BF16) {
-        rc = conv_wgrad_bf16(d, nsplit, nci, nco, tilesX, tilesY, ntiles, s);
+        const int used = conv_wgrad_bf16(d, nsplit, nci, nco, tilesX, tilesY, ntiles, s);
+        rc = check_launch("conv_wgrad_bf16");
+        if (used > 0) nsplit = used;     // 64-ci workgroups use a different pixel split
     } else {
         if (d.ksize == 3)
             hipLaunchKernelGGL((wgrad_f32_kernel<3>), grid, dim3(256), 0, s, d, tilesX, tilesY, ntiles, nci, nco);
@@ -520,7 +522,7 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     if (rc) return rc;
     if (d.dbias) {
         // bias_part[split][coc][32] written by the ci-chunk-0 workgroups; channel = coc*32 + lane
-        const float* bp = d.workspace + (size_t)WGRAD_MAX_WG * 9 * WG_C * WG_C;
+        const float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(ceil_div(d.cout, 4)), dim3(256), 0, s, bp, nsplit, nco,
                            d.cout, d.alpha, d.accumulate, d.dbias);
         rc = check_launch("conv_wgrad_bias_reduce");
