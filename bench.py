@@ -32,6 +32,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak 
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel: str, batch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE collected
+    in two separate passes of this script at the default batch, corrected as MI355X_MICROARCH.md prescribes).
+    bench.py cannot collect PMC counters itself; returns None when no matching summary exists."""
+    path = os.path.join(REPO, "profiles", "r01_bf16_traffic_pmc.json")
+    if batch != 4 or not os.path.exists(path):
+        return None
+    try:
+        blob = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    v = blob.get(kernel)
+    return v["hbm_bytes_per_launch"] / 1e9 if v else None
+
+
 def host_cores() -> int:
     """CPU threads this process may really use: affinity mask capped by the cgroup quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -199,7 +214,11 @@ def main():
             name, d = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])
             tflops = d["flops"] / (d["ms_total"] * 1e-3) / 1e12
             gbs = d["bytes"] / (d["ms_total"] * 1e-3) / 1e9
-            common = {"traffic": None, "kernel": name, "launches": d["launches"],
+            traffic = pmc_traffic(name, B) if args.math == "bf16" and not args.fp32_acts else None
+            common = {"traffic": traffic, "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
+                                                          "profiles/r01_bf16_traffic_pmc.json)" if traffic else None,
+                      "algorithmic_gb_per_launch": d["bytes"] / d["launches"] / 1e9,
+                      "kernel": name, "launches": d["launches"],
                       "avg_launch_ms": d["ms_total"] / d["launches"],
                       "share_of_step": d["ms_total"] / (dt_b * 1e3),
                       "measured": "second pass of the same K steps with a HIP event pair around each conv launch"}
