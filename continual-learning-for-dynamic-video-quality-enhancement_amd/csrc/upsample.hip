@@ -75,6 +75,34 @@ __global__ __launch_bounds__(256) void shuffle_clamp_bwd_kernel(const float* __r
     for (int k = K; k < du_ld; ++k) dp[k] = 0.f;
 }
 
+// out = strength * sr + (1 - strength) * bicubic(frames[:, t_center])   (EnhancementEngine strength < 1 blend)
+__global__ __launch_bounds__(256) void bicubic_blend_kernel(const float* __restrict__ sr,
+                                                            const float* __restrict__ frames, int T, int t_center,
+                                                            int Cimg, int H, int W, int s, float scale, float strength,
+                                                            float* __restrict__ out, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int OW = W * s, OH = H * s;
+    const int ox = gid % OW;
+    const int oy = (gid / OW) % OH;
+    const int b = gid / ((long)OW * OH);
+    int xi[4], yi[4];
+    float wx[4], wy[4];
+    cubic_taps(ox, scale, W, xi, wx);
+    cubic_taps(oy, scale, H, yi, wy);
+    for (int c = 0; c < Cimg; ++c) {
+        const float* img = frames + ((size_t)(b * T + t_center) * Cimg + c) * H * W;
+        float bic = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float* row = img + (size_t)yi[a] * W;
+            bic += wy[a] * (wx[0] * row[xi[0]] + wx[1] * row[xi[1]] + wx[2] * row[xi[2]] + wx[3] * row[xi[3]]);
+        }
+        const size_t o = ((size_t)(b * Cimg + c) * OH + oy) * OW + ox;
+        out[o] = strength * sr[o] + (1.f - strength) * bic;
+    }
+}
+
 }  // namespace nvq
 
 using namespace nvq;
@@ -89,6 +117,15 @@ int nvq_shuffle_bicubic_clamp(const float* u, int u_ld, const float* frames, int
     hipLaunchKernelGGL(shuffle_bicubic_clamp_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, u,
                        u_ld, frames, T, t_center, Cimg, H, W, s, scale, out, pass, total);
     return check_launch("shuffle_bicubic_clamp");
+}
+
+int nvq_bicubic_blend(const float* sr, const float* frames, int B, int T, int t_center, int Cimg, int H, int W, int s,
+                      float strength, float* out, void* stream) {
+    NVQ_REQUIRE(s >= 1 && s <= 8 && t_center >= 0 && t_center < T, "bicubic_blend: args");
+    const long total = (long)B * H * s * W * s;
+    hipLaunchKernelGGL(bicubic_blend_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, sr, frames, T,
+                       t_center, Cimg, H, W, s, (float)(1.0 / (double)s), strength, out, total);
+    return check_launch("bicubic_blend");
 }
 
 int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H, int W, int s,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "nvq_cbam_bwd_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_clamp_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_bicubic_blend": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]),
     "nvq_axpy_slice": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, cl, cf, ci, vp]),
     "nvq_colsum": (ci, [vp, ci, ci, ci, cl, cf, vp, vp, sz, ci, vp]),
     "nvq_ewc_penalty": (ci, [vp, vp, vp, cl, cf, vp, vp, sz, vp]),
@@ -497,6 +498,12 @@ def shuffle_clamp_backward(dout: torch.Tensor, passmask, s: int, du: torch.Tenso
     B, Cimg, OH, OW = dout.shape
     check(lib().nvq_shuffle_clamp_backward(ptr(dout), ptr(passmask), B, Cimg, OH // s, OW // s, s, ptr(du),
                                            du.shape[-1], stream()), "nvq_shuffle_clamp_backward")
+
+
+def bicubic_blend(sr: torch.Tensor, frames: torch.Tensor, t_center: int, s: int, strength: float, out: torch.Tensor):
+    B, T, Cimg, H, W = frames.shape
+    check(lib().nvq_bicubic_blend(ptr(sr), ptr(frames), B, T, t_center, Cimg, H, W, s, float(strength), ptr(out),
+                                  stream()), "nvq_bicubic_blend")
 
 
 # ----------------------------------------------------------------------------- helpers

@@ -15,7 +15,23 @@ from typing import Any, Dict, Optional
 import torch
 import torch.nn as nn
 
+from nerve_cl import _nvq
 from nerve_cl.models.super_resolution import SuperResolutionNet
+
+
+class _BlendFn(torch.autograd.Function):
+    """strength * sr + (1 - strength) * bicubic(frame): one kernel; the frame carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, sr, frames, t_center, scale, strength):
+        out = torch.empty_like(sr)
+        _nvq.bicubic_blend(sr.contiguous(), frames, t_center, scale, strength, out)
+        ctx.strength = strength
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.strength, None, None, None, None
 
 
 @dataclass
@@ -81,9 +97,28 @@ class EnhancementEngine(nn.Module):
             results["super_resolved"] = current
         strength = enhancement_strength if enhancement_strength is not None else self.enhancement_strength.item()
         if strength < 1.0 and "super_resolved" in results:
-            raise NotImplementedError("strength < 1 bicubic blending is a 'next' row (SURVEY.md 8f row 2)")
+            # blend with the bicubic-upsampled original (reference :172-180)
+            current = _BlendFn.apply(current, frames.detach().to(torch.float32).contiguous(), center_idx,
+                                     self.config.scale_factor, float(strength))
         results["enhanced"] = current
         return results
+
+    def enhance_video(self, video: torch.Tensor, corruption_masks: Optional[torch.Tensor] = None,
+                      batch_size: int = 4) -> torch.Tensor:
+        """Sliding-window enhancement of a whole clip, (T,C,H,W) or (B,T,C,H,W) -> same rank, upscaled
+        (reference :186-248: window = 2*max(recovery window, sr window)+1, clipped at the clip boundaries)."""
+        squeeze = video.dim() == 4
+        if squeeze:
+            video = video.unsqueeze(0)
+        B, T, C, H, W = video.shape
+        win = 2 * max(self.config.recovery_temporal_window, self.config.sr_temporal_window) + 1
+        frames_out = []
+        for t in range(T):
+            lo, hi = max(0, t - win // 2), min(T, t + win // 2 + 1)
+            mask = corruption_masks[t:t + 1] if corruption_masks is not None else None
+            frames_out.append(self.forward(video[:, lo:hi], center_idx=t - lo, corruption_mask=mask)["enhanced"])
+        out = torch.stack(frames_out, dim=1)
+        return out.squeeze(0) if squeeze else out
 
     def get_model_info(self) -> Dict[str, Any]:
         info: Dict[str, Any] = {

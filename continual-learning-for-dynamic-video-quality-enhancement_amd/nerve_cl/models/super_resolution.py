@@ -10,6 +10,7 @@ all-reduces over RCCL, see ``nerve_cl.parallel``).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -135,8 +136,10 @@ class SuperResolutionNet(nn.Module):
         # (fp32 = the parity mode, 1e-3 of the CPU path; bf16 = the throughput mode of BASELINE cfg2).
         # bf16_activations: additionally store the conv-internal tensors (dense-block buffers, flow-net and
         # attention hidden activations, their gradients) as bf16; only honoured with math_mode = MATH_BF16.
-        self.math_mode = _nvq.MATH_F32
-        self.bf16_activations = False
+        # Environment default (for unmodified caller scripts): NVQ_MATH=bf16 selects the throughput mode.
+        bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
+        self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
+        self.bf16_activations = bf16 and os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
         self._param_names: List[str] = [n for n, _ in self.named_parameters()]
         self._grad_bucket_hook = None
         self._last_intermediates = None

@@ -267,6 +267,11 @@ int nvq_cbam_bwd_channel(const float* dca_partial, int nblk, int C, int R, int N
 int nvq_shuffle_bicubic_clamp(const float* u, int u_ld, const float* frames, int B, int T,
                               int t_center, int Cimg, int H, int W, int s, float* out,
                               uint8_t* pass, void* stream);
+/* EnhancementEngine strength blend, enhancement_engine.py:172-180:
+ * out = strength * sr + (1 - strength) * F.interpolate(frames[:, t_center], bicubic, align_corners=False).
+ * sr / out: fp32 NCHW (B,Cimg,H*s,W*s); frames: fp32 (B,T,Cimg,H,W). */
+int nvq_bicubic_blend(const float* sr, const float* frames, int B, int T, int t_center, int Cimg,
+                      int H, int W, int s, float strength, float* out, void* stream);
 /* du[b,h,w,c*s*s+i*s+j] = dout[b,c,h*s+i,w*s+j] * pass ; channels up to u_ld zero-filled */
 int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H,
                                int W, int s, float* du, int du_ld, void* stream);

@@ -125,3 +125,26 @@ def test_engine_dict_surface_on_gpu():
     assert all(p.grad is not None for p in eng.super_resolution.parameters())
     short = eng(frames[:, :2], center_idx=1)          # right-padded by repeating the last frame
     assert short["enhanced"].shape == (1, 3, 128, 128)
+
+
+def test_engine_strength_blend_and_enhance_video():
+    """strength < 1 blends with the bicubic-upsampled centre frame (reference enhancement_engine.py:172-180);
+    enhance_video slides the window over a clip (:186-248)."""
+    import torch.nn.functional as F
+    from nerve_cl.models import EnhancementConfig, EnhancementEngine
+    torch.manual_seed(0)
+    eng = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True,
+                                              sr_num_features=16, sr_num_residual_blocks=1)).cuda().eval()
+    frames = torch.rand(2, 3, 3, 20, 28, device="cuda")
+    full = eng(frames)["enhanced"]
+    half = eng(frames, enhancement_strength=0.25)
+    want = 0.25 * half["super_resolved"] + 0.75 * F.interpolate(frames[:, 1].cpu(), size=(40, 56), mode="bicubic",
+                                                                align_corners=False).cuda()
+    assert torch.equal(half["super_resolved"], full)
+    assert (half["enhanced"] - want).abs().max().item() < 2e-6
+    half["enhanced"].sum().backward()
+    g = next(eng.super_resolution.parameters()).grad
+    assert g is not None and torch.isfinite(g).all()
+    with torch.no_grad():
+        vid = eng.enhance_video(torch.rand(5, 3, 16, 16, device="cuda"))
+    assert vid.shape == (5, 3, 32, 32)
