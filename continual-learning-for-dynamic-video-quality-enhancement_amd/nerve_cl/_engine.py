@@ -343,6 +343,82 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                  G["feature_extractor.head.0.bias"], ws)
 
 
+# ----------------------------------------------------------------------------- LightweightSuperResolution
+LIGHT_F = 32
+LIGHT_BLOCKS = (2, 3, 4, 5)       # indices of the DepthwiseSeparableConv modules inside `net`
+
+
+def light_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, scale: int, training: bool, math: int = K.MATH_F32,
+                  act_dtype: torch.dtype = torch.float32) -> "tuple[torch.Tensor, Saved]":
+    """Single-frame net (reference super_resolution.py:434-470): conv3x3+ReLU, four depthwise-separable blocks,
+    conv3x3 -> PixelShuffle, + bicubic(x), clamp.  Same kernels as the SR feature extractor and tail."""
+    assert act_dtype == torch.float32 or math == K.MATH_BF16
+    dev = x.device
+    B, Cimg, H, W = x.shape
+    F = LIGHT_F
+    frames = x.view(B, 1, Cimg, H, W)
+    ws = workspace(dev)
+    sv = Saved()
+    sv.frames, sv.training, sv.math, sv.act_dtype, sv.scale = frames, training, math, act_dtype, scale
+    feat0 = _new(dev, B, H, W, F)
+    K.head_forward(frames, [0], P["net.0.weight"], P["net.0.bias"], feat0)
+    sv.feat0, sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = feat0, [], [], [], [], []
+    cur = feat0
+    for k in LIGHT_BLOCKS:
+        pre = f"net.{k}."
+        d = _new(dev, B, H, W, F, dtype=act_dtype)
+        K.dwconv_forward(cur, P[pre + "depthwise.weight"], d)
+        p = _new(dev, B, H, W, F, dtype=act_dtype)
+        K.conv_forward(Sl(d), K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math), None, Sl(p), 1, math=math)
+        mean, invstd = _new(dev, 1, F), _new(dev, 1, F)
+        if training:
+            K.bn_stats(p, B, [0], mean, invstd, P[pre + "bn.running_mean"], P[pre + "bn.running_var"], ws, BN_EPS, BN_MOM)
+            P[pre + "bn.num_batches_tracked"].add_(1)
+        else:
+            K.bn_eval_stats(P[pre + "bn.running_mean"], P[pre + "bn.running_var"], 1, mean, invstd, BN_EPS)
+        r = _new(dev, B, H, W, F, dtype=act_dtype)
+        K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], None, Sl(r), B)
+        sv.dws.append(d); sv.pws.append(p); sv.acts.append(r); sv.bn_mean.append(mean); sv.bn_invstd.append(invstd)
+        cur = r
+    U = Cimg * scale * scale
+    Up = K.pad4(U)
+    u = _new(dev, B, H, W, Up)
+    K.conv_forward(Sl(cur), K.conv_pack(P["net.6.weight"], False, F, math=math), P["net.6.bias"], Sl(u, U), 3,
+                   cout_store=Up, math=math)
+    out = _new(dev, B, Cimg, H * scale, W * scale)
+    passmask = _new(dev, B, Cimg, H * scale, W * scale, dtype=torch.uint8)
+    K.shuffle_bicubic_clamp(u, frames, 0, scale, out, passmask)
+    sv.passmask, sv.U, sv.Up = passmask, U, Up
+    return out, sv
+
+
+def light_backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[str, torch.Tensor]) -> None:
+    dev = dout.device
+    B, _, Cimg, H, W = sv.frames.shape
+    F, math, act_dtype = LIGHT_F, sv.math, sv.act_dtype
+    ws = workspace(dev)
+    du = _new(dev, B, H, W, sv.Up)
+    K.shuffle_clamp_backward(dout, sv.passmask, sv.scale, du)
+    last = sv.acts[-1]
+    _wgrad(Sl(last), F, Sl(du, sv.U), G, "net.6.weight", "net.6.bias", ws, 3, math=math)
+    dcur = _new(dev, B, H, W, F)
+    K.conv_forward(Sl(du), K.conv_pack(P["net.6.weight"], True, sv.Up, F, math=math), None, Sl(dcur), 3, math=math)
+    for j in range(len(LIGHT_BLOCKS) - 1, -1, -1):
+        pre = f"net.{LIGHT_BLOCKS[j]}."
+        dp = _new(dev, B, H, W, F, dtype=act_dtype)
+        K.bn_relu_backward(dcur, sv.pws[j], B, sv.bn_mean[j], sv.bn_invstd[j], P[pre + "bn.weight"], P[pre + "bn.bias"],
+                           sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
+        _wgrad(Sl(sv.dws[j]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
+        dd = _new(dev, B, H, W, F, dtype=act_dtype)
+        K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
+        xin = sv.feat0 if j == 0 else sv.acts[j - 1]
+        K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws)
+        dx = _new(dev, B, H, W, F, dtype=act_dtype if j > 0 else torch.float32)
+        K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
+        dcur = dx
+    K.head_wgrad(sv.frames, [0], dcur, sv.feat0, G["net.0.weight"], G["net.0.bias"], ws)
+
+
 def nhwc_to_nchw(t: torch.Tensor, c: Optional[int] = None, coff: int = 0) -> torch.Tensor:
     c = t.shape[-1] - coff if c is None else c
     return t[..., coff:coff + c].permute(0, 3, 1, 2).contiguous().float()

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from nerve_cl import _nvq
-from nerve_cl.models.super_resolution import SuperResolutionNet
+from nerve_cl.models.super_resolution import LightweightSuperResolution, SuperResolutionNet
 
 
 class _BlendFn(torch.autograd.Function):
@@ -60,13 +60,14 @@ class EnhancementEngine(nn.Module):
         self._frame_recovery_requested = bool(self.config.frame_recovery_enabled)
         if self.config.super_resolution_enabled:
             if self.config.use_lightweight_sr:
-                raise NotImplementedError("use_lightweight_sr is outside the MI355X hot path built so far")
-            self.super_resolution = SuperResolutionNet(
-                scale_factor=self.config.scale_factor,
-                num_features=self.config.sr_num_features,
-                num_residual_blocks=self.config.sr_num_residual_blocks,
-                temporal_window=self.config.sr_temporal_window,
-            )
+                self.super_resolution = LightweightSuperResolution(scale_factor=self.config.scale_factor)
+            else:
+                self.super_resolution = SuperResolutionNet(
+                    scale_factor=self.config.scale_factor,
+                    num_features=self.config.sr_num_features,
+                    num_residual_blocks=self.config.sr_num_residual_blocks,
+                    temporal_window=self.config.sr_temporal_window,
+                )
         else:
             self.super_resolution = None
         self.enhancement_strength = nn.Parameter(torch.ones(1))
@@ -93,7 +94,10 @@ class EnhancementEngine(nn.Module):
             if sr_frames.shape[1] < need:   # right-pad by repeating the last frame (:152-158)
                 sr_frames = torch.cat(
                     [sr_frames, sr_frames[:, -1:].expand(-1, need - sr_frames.shape[1], -1, -1, -1)], dim=1)
-            current = self.super_resolution(sr_frames)
+            if isinstance(self.super_resolution, LightweightSuperResolution):
+                current = self.super_resolution(current)      # single-frame net (:161-162)
+            else:
+                current = self.super_resolution(sr_frames)
             results["super_resolved"] = current
         strength = enhancement_strength if enhancement_strength is not None else self.enhancement_strength.item()
         if strength < 1.0 and "super_resolved" in results:
@@ -134,7 +138,7 @@ class EnhancementEngine(nn.Module):
             },
         }
         if self.super_resolution is not None:
-            info["parameters"]["super_resolution"] = self.super_resolution.get_num_parameters()
+            info["parameters"]["super_resolution"] = sum(p.numel() for p in self.super_resolution.parameters())
         return info
 
     def set_enhancement_mode(self, mode: str) -> None:

@@ -206,10 +206,57 @@ class SuperResolutionNet(nn.Module):
         return flops
 
 
+class _LightFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: "LightweightSuperResolution", x: torch.Tensor, *params):
+        act = torch.bfloat16 if (net.bf16_activations and net.math_mode == _nvq.MATH_BF16) else torch.float32
+        out, sv = _engine.light_forward(net._tensor_dict(), x, net.scale_factor, net.training, net.math_mode, act)
+        ctx.net = net
+        ctx.sv = sv if any(ctx.needs_input_grad[2:]) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net, sv = ctx.net, ctx.sv
+        if sv is None:
+            raise RuntimeError("LightweightSuperResolution backward called without saved forward state")
+        flat, views = SuperResolutionNet._new_grad_bucket(net)
+        _engine.light_backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
+        ctx.sv = None
+        if net._grad_bucket_hook is not None:
+            net._grad_bucket_hook(flat)
+        net._last_grad_bucket = flat
+        return (None, None) + tuple(views[n] for n in net._param_names)
+
+
 class LightweightSuperResolution(nn.Module):
-    """Single-frame variant of the reference (:434-470).  Not on the accelerated path yet."""
+    """Single-frame variant (reference :434-470): conv3x3+ReLU, 4 depthwise-separable blocks (32 features),
+    conv3x3 -> PixelShuffle, + bicubic(x), clamp.  ``state_dict`` keys are the reference's (``net.<i>.*``)."""
 
     def __init__(self, scale_factor: int = 2):
         super().__init__()
-        raise NotImplementedError(
-            "LightweightSuperResolution is outside the MI355X hot path built so far (SURVEY.md 8f row 2)")
+        self.scale_factor = scale_factor
+        F = _engine.LIGHT_F
+        self.net = Stack(nn.Conv2d(3, F, 3, 1, 1), Act(),
+                         DepthwiseSeparableConv(F, F), DepthwiseSeparableConv(F, F),
+                         DepthwiseSeparableConv(F, F), DepthwiseSeparableConv(F, F),
+                         nn.Conv2d(F, 3 * scale_factor ** 2, 3, 1, 1), Act())
+        self.bicubic = Act()
+        bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
+        self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
+        self.bf16_activations = bf16 and os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
+        self._param_names: List[str] = [n for n, _ in self.named_parameters()]
+        self._grad_bucket_hook = None
+        self._last_grad_bucket = None
+
+    _tensor_dict = SuperResolutionNet._tensor_dict
+    _bucket_layout = SuperResolutionNet._bucket_layout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,3,H,W) -> (B,3,H*s,W*s)."""
+        _nvq.require_device(x, "x")
+        _nvq.require_device(next(self.parameters()), "LightweightSuperResolution parameters")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"expected (B,3,H,W), got {tuple(x.shape)}")
+        params = [p for _, p in self.named_parameters()]
+        return _LightFunction.apply(self, x.detach().to(torch.float32).contiguous(), *params)

@@ -231,11 +231,55 @@ def run_default_init(RefSR):
     print("default init:", len(blob), "tensors")
 
 
+LIGHT_CASES = {"light_s2_train": (2, 2, 12, 20, True), "light_s3_eval": (3, 1, 9, 14, False)}
+
+
+def run_light(name, cfg):
+    """LightweightSuperResolution (reference super_resolution.py:434-470): output, loss, gradients, BN buffers."""
+    from nerve_cl.models import LightweightSuperResolution as RefLight
+    s, B, H, W, train = cfg
+    sd = synth.formula_state_light(s, gain=GAIN)
+    x = synth.formula_clip(B, 1, H, W)[:, 0].contiguous()
+    tgt = synth.formula_target(B, H * s, W * s)
+    ref = RefLight(s)
+    ref.load_state_dict(sd, strict=True)
+    ref.train(train)
+    out = ref(x)
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    o_out = sr_oracle.light_forward(P, x, train)
+    F.mse_loss(o_out, tgt).backward()
+    err = (o_out - out).abs().max().item()
+    assert err < 2e-5, f"{name}: oracle != reference output {err:.3e}"
+    ref_sd = ref.state_dict()
+    for n, p in ref.named_parameters():
+        e = (P[n].grad - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        assert e < 1e-4, f"{name}: oracle != reference grad {n} {e:.3e}"
+    for n in sr_oracle.light_buffer_shapes():
+        assert (P[n].double() - ref_sd[n].double()).abs().max().item() < 1e-5, n
+    blob = {"cfg": np.array([s, B, H, W, int(train)], dtype=np.int64), "output": out.detach().numpy(),
+            "loss": np.array(loss.item(), dtype=np.float64),
+            "clamped_frac": np.array(((out == 0) | (out == 1)).float().mean().item())}
+    for n, p in ref.named_parameters():
+        blob["gsum/" + n] = grad_summary(p.grad)
+        if p.grad.numel() <= 256:
+            blob["gfull/" + n] = p.grad.detach().numpy()
+    for n in sr_oracle.light_buffer_shapes():
+        blob["buf/" + n] = ref_sd[n].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
+    print(f"{name}: loss {loss.item():.6f} clamped {blob['clamped_frac']:.3f} oracle-vs-ref out err {err:.2e}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     RefSR, RefEWC = import_reference()
+    for name, cfg in LIGHT_CASES.items():
+        run_light(name, cfg)
+    if "--only-light" in sys.argv:
+        return
     for name, cfg in CASES.items():
         run_case(name, cfg, RefSR)
     run_trajectory(RefSR)

@@ -213,6 +213,46 @@ def bicubic_up(x: torch.Tensor, s: int) -> torch.Tensor:
     return F.interpolate(x, scale_factor=float(s), mode="bicubic", align_corners=False)
 
 
+LIGHT_F = 32
+LIGHT_BLOCKS = (2, 3, 4, 5)
+
+
+def light_param_shapes(scale_factor: int = 2) -> Dict[str, tuple]:
+    """state_dict parameter names / shapes of LightweightSuperResolution, super_resolution.py:450-459."""
+    Fc = LIGHT_F
+    sh = {"net.0.weight": (Fc, 3, 3, 3), "net.0.bias": (Fc,)}
+    for k in LIGHT_BLOCKS:
+        sh[f"net.{k}.depthwise.weight"] = (Fc, 1, 3, 3)
+        sh[f"net.{k}.pointwise.weight"] = (Fc, Fc, 1, 1)
+        sh[f"net.{k}.bn.weight"] = (Fc,)
+        sh[f"net.{k}.bn.bias"] = (Fc,)
+    sh["net.6.weight"] = (3 * scale_factor ** 2, Fc, 3, 3)
+    sh["net.6.bias"] = (3 * scale_factor ** 2,)
+    return sh
+
+
+def light_buffer_shapes() -> Dict[str, tuple]:
+    sh = {}
+    for k in LIGHT_BLOCKS:
+        sh[f"net.{k}.bn.running_mean"] = (LIGHT_F,)
+        sh[f"net.{k}.bn.running_var"] = (LIGHT_F,)
+        sh[f"net.{k}.bn.num_batches_tracked"] = ()
+    return sh
+
+
+def light_forward(P: Params, x: torch.Tensor, training: bool = True) -> torch.Tensor:
+    """LightweightSuperResolution.forward, super_resolution.py:467-470 (net: :450-459)."""
+    y = F.relu(F.conv2d(x, P["net.0.weight"], P["net.0.bias"], padding=1))
+    for k in LIGHT_BLOCKS:
+        b = f"net.{k}."
+        y = F.conv2d(y, P[b + "depthwise.weight"], None, padding=1, groups=y.shape[1])
+        y = F.conv2d(y, P[b + "pointwise.weight"], None)
+        y = F.relu(batch_norm_call(y, P, b + "bn.", training))
+    y = F.conv2d(y, P["net.6.weight"], P["net.6.bias"], padding=1)
+    s = int(round(math.sqrt(P["net.6.weight"].shape[0] / 3)))
+    return torch.clamp(bicubic_up(x, s) + F.pixel_shuffle(y, s), 0, 1)
+
+
 def num_blocks(P: Params) -> int:
     k = 0
     while f"residual_blocks.{k}.lff.weight" in P:

@@ -36,9 +36,18 @@ def formula_state(in_channels=3, scale_factor=2, num_features=64, num_residual_b
     variance for unit-variance input), biases U(-0.1, 0.1), BN weight in
     [0.8, 1.2], BN bias in [-0.1, 0.1], running_mean in [-0.2, 0.2], running_var
     in [0.5, 1.5], num_batches_tracked = 3."""
-    sd: Dict[str, torch.Tensor] = {}
     shapes = sr_oracle.param_shapes(in_channels, scale_factor, num_features,
                                     num_residual_blocks, temporal_window)
+    return _fill(shapes, sr_oracle.buffer_shapes(num_features), gain)
+
+
+def formula_state_light(scale_factor: int = 2, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Same recipe for LightweightSuperResolution's state_dict."""
+    return _fill(sr_oracle.light_param_shapes(scale_factor), sr_oracle.light_buffer_shapes(), gain)
+
+
+def _fill(shapes, buffers, gain) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
     for name, shp in shapes.items():
         n = int(np.prod(shp))
         u = hash01(n, name_seed(name)) * 2 - 1
@@ -50,7 +59,7 @@ def formula_state(in_channels=3, scale_factor=2, num_features=64, num_residual_b
             fan_in = int(np.prod(shp[1:]))
             v = gain * np.sqrt(3.0 / fan_in) * u
         sd[name] = torch.from_numpy(v.reshape(shp).astype(np.float32))
-    for name, shp in sr_oracle.buffer_shapes(num_features).items():
+    for name, shp in buffers.items():
         if name.endswith("num_batches_tracked"):
             sd[name] = torch.tensor(3, dtype=torch.long)
             continue

@@ -109,3 +109,31 @@ def test_bicubic_phase_weights():
     assert abs(y[9].item() - 0.87890625) < 1e-7
     assert abs(y[10].item() - 0.26171875) < 1e-7
     assert abs(y[7].item() - 0.26171875) < 1e-7
+
+
+LIGHT = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "light_*.npz")))
+
+
+@pytest.mark.parametrize("path", LIGHT, ids=[os.path.basename(p)[:-4] for p in LIGHT])
+def test_light_matches_reference_fixture(path):
+    """LightweightSuperResolution restatement (oracle light_forward) against the reference's numbers."""
+    g = np.load(path)
+    s, B, H, W, train = [int(v) for v in g["cfg"]]
+    sd = synth.formula_state_light(s, gain=synth.GOLDEN_GAIN)
+    x = synth.formula_clip(B, 1, H, W)[:, 0].contiguous()
+    tgt = synth.formula_target(B, H * s, W * s)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = sr_oracle.light_forward(P, x, bool(train))
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+    assert _rel(out.detach().numpy(), g["output"]) < 1e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    for key in g.files:
+        if key.startswith("gsum/"):
+            ref, got = g[key], grad_summary(P[key[5:]].grad)
+            assert abs(got[1] - ref[1]) <= 1e-4 * max(ref[1], 1e-12), key
+            assert np.abs(got[2:] - ref[2:]).max() <= 1e-4 * max(np.abs(ref[2:]).max(), ref[1] * 1e-2), key
+        elif key.startswith("gfull/"):
+            assert _rel(P[key[6:]].grad.numpy(), g[key]) < 1e-4, key
+        elif key.startswith("buf/"):
+            assert _rel(P[key[4:]].double().numpy(), g[key]) < 1e-5, key

@@ -284,3 +284,50 @@ def test_bf16_activation_storage_quality(SR):
         o2.zero_grad(); b = F.mse_loss(ora2(x), tgt); b.backward(); o2.step(); l2.append(b.item())
     print("  bf16 storage losses", l1, "fp32 oracle", l2)
     assert np.allclose(l1, l2, rtol=1e-2)
+
+
+LIGHT = sorted(glob.glob(os.path.join(GOLD, "light_*.npz")))
+
+
+@pytest.mark.parametrize("path", LIGHT, ids=[os.path.basename(p)[:-4] for p in LIGHT])
+def test_lightweight_against_reference_fixture_and_oracle(SR, path):
+    """LightweightSuperResolution (reference super_resolution.py:434-470) through the HIP kernels: output, loss,
+    every gradient and the BN running statistics against the reference fixture and the oracle."""
+    from nerve_cl.models import LightweightSuperResolution
+    g = np.load(path)
+    s, B, H, W, train = [int(v) for v in g["cfg"]]
+    sd = synth.formula_state_light(s, gain=synth.GOLDEN_GAIN)
+    net = LightweightSuperResolution(s)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train(bool(train))
+    x = synth.formula_clip(B, 1, H, W)[:, 0].contiguous()
+    tgt = synth.formula_target(B, H * s, W * s)
+    out = net(x.cuda())
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    assert rel(out, g["output"]) < REL
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    F.mse_loss(sr_oracle.light_forward(P, x, bool(train)), tgt).backward()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        e = rel(p.grad, P[n].grad)
+        worst = max(worst, e)
+        assert e < REL, (n, e)
+        if "gfull/" + n in g.files:
+            assert rel(p.grad, g["gfull/" + n]) < REL, n
+        ref = g["gsum/" + n]
+        got = grad_summary(p.grad.cpu())
+        assert abs(got[1] - ref[1]) <= REL * max(ref[1], 1e-12), n
+    for n, b in net.named_buffers():
+        assert rel(b.double(), g["buf/" + n]) < 1e-5, n
+    print(f"light {os.path.basename(path)}: worst grad rel {worst:.2e}")
+    # eval-mode inference through EnhancementEngine(use_lightweight_sr)
+    from nerve_cl.models import EnhancementConfig, EnhancementEngine
+    eng = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, use_lightweight_sr=True, scale_factor=s))
+    eng.super_resolution.load_state_dict(net.state_dict())
+    eng = eng.cuda().eval()
+    with torch.no_grad():
+        y = eng(x.cuda().unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+        assert torch.equal(y, net.eval()(x.cuda()))
