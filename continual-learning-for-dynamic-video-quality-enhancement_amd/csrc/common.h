@@ -69,6 +69,15 @@ __device__ __forceinline__ float block_sum_256(float v, float* scratch) {
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own 4 MiB L2.  Tile kernels map
+// workgroup `bid` of `n` to tile xcd_tile(bid, n): a bijection on [0, n) that gives every XCD one contiguous range of
+// tiles, so the halo a tile shares with its neighbours is an L2 hit instead of a second HBM read.  Persistent kernels
+// pass bid + k * gridDim.x (gridDim.x a multiple of 8): a workgroup then walks its own XCD's range.
+__device__ __forceinline__ int xcd_tile(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7;
+    return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
 // Second stage of every two-stage reduction in the library:
 // out[k] = alpha * sum_b part[b*K + k] (+ out[k]); summed in double, fixed order => deterministic.
 int launch_reduce_partials(const float* part, int nblk, int K, float alpha, float* out,

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
     const int c = lane & 15;
     const int g = lane >> 4;
 
-    int bt = blockIdx.x;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
@@ -174,23 +174,53 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
         __syncthreads();
         if (kc + 1 < nkc && dbg != 2) fetch(kc + 1);
         if (dbg == 1) continue;
+        // Fragment reads software-pipelined against the MFMAs (the compiler otherwise emits read -> lgkmcnt(0) ->
+        // 4 MFMAs, exposing the LDS latency 2*TAPS times per chunk).  Stages run dx-major, dy-minor: going from dy to
+        // dy+1 the wave's upper output row reuses the fragments of the lower one, so a stage needs only the two
+        // fragments of one new halo row; those, and the next stage's weights, are read one stage ahead.
+        auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
+        };
+        auto ldW = [&](int tap, int cb) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+        };
+        bf16x8 lo[2], hi[2], wa[NB], wn[NB];
+        lo[0] = ldP(0, 0, 0); lo[1] = ldP(0, 1, 0);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = tap / KS, dx = tap - dy * KS;
-            bf16x8 xb[4];
+        for (int cb = 0; cb < NB; ++cb) wa[cb] = ldW(0, cb);
+        hi[0] = ldP(1, 0, 0); hi[1] = ldP(1, 1, 0);
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                const int row = 2 * wave + (pb >> 1);
-                const int x0 = (pb & 1) * 16;
-                const int hp = (row + dy) * HW_ + x0 + c + dx;
-                xb[pb] = *reinterpret_cast<const bf16x8*>(xs + hp * XSB + 8 * g);
+        for (int s = 0; s < TAPS; ++s) {
+            const int dy = s % KS;
+            const bool last = s + 1 == TAPS;
+            const int ndx = (s + 1) / KS, ndy = (s + 1) % KS;
+            const bool same_dx = !last && ndy != 0;
+            bf16x8 nlo[2], nhi[2];
+            if (!last) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) wn[cb] = ldW(ndy * KS + ndx, cb);
             }
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-                const bf16x8 wa = *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+            for (int xh = 0; xh < 2; ++xh) {
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[pb], acc[cb][pb], 0, 0, 0);
+                for (int cb = 0; cb < NB; ++cb)
+                    acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], lo[xh], acc[cb][xh], 0, 0, 0);
+                if (same_dx) nhi[xh] = ldP(dy + 2, xh, ndx);
+                else if (!last) nlo[xh] = ldP(0, xh, ndx);
+            }
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb)
+                    acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], hi[xh], acc[cb][2 + xh], 0, 0, 0);
+                if (same_dx) nlo[xh] = hi[xh];
+                else if (!last) nhi[xh] = ldP(1, xh, ndx);
+            }
+            if (!last) {
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) { lo[xh] = nlo[xh]; hi[xh] = nhi[xh]; }
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) wa[cb] = wn[cb];
             }
         }
     }
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     // commit(), so that nothing between the prefetch and the next commit uses a loaded value
     unsigned xmask = 0, ymask = 0;
     auto fetch = [&](int tile) {
-        int bt = tile;
+        int bt = xcd_tile(tile, ntiles);
         const int tx = bt % tilesX; bt /= tilesX;
         const int ty = bt % tilesY;
         const int n = bt / tilesY;
@@ -443,6 +473,7 @@ int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int t
         nsplit = WGRAD_MAX_WG / (ncig * nco);
         if (nsplit < 1) nsplit = 1;
         if (nsplit > ntiles) nsplit = ntiles;
+        if (nsplit >= 8) nsplit &= ~7;      // multiple of the XCD count: see xcd_tile()
     }
     const dim3 grid(nsplit, ncig, nco);
 #define NVQ_LAUNCH_WG(KS, XB, YB, CIC) \

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
     const int c = lane & 15;
     const int g = lane >> 4;
 
-    int bt = blockIdx.x;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of dy, channels 4*(tid&7)..+3 (bias gradient)
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int bt = tile;
+        int bt = xcd_tile(tile, ntiles);
         const int tx = bt % tilesX; bt /= tilesX;
         const int ty = bt % tilesY;
         const int n = bt / tilesY;
@@ -496,6 +496,7 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     int nsplit = WGRAD_MAX_WG / (nci * nco);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
+    if (nsplit >= 8) nsplit &= ~7;      // multiple of the XCD count: see xcd_tile()
     NVQ_REQUIRE((size_t)nsplit * nci * nco * taps * WG_C * WG_C * sizeof(float) <= d.workspace_bytes,
                 "conv_wgrad: %d x %d channel chunks exceed the workspace", nci, nco);
     hipStream_t s = (hipStream_t)stream;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const float* __restrict__
                                                        int x2_images, int C, int H, int W, int tilesX,
                                                        int tilesY, float* __restrict__ out, int out_ld) {
     __shared__ __attribute__((aligned(16))) float xs[CHH * CHW * CLD];
-    int bt = blockIdx.x;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const float* __restrict__
                                                        int tilesY, float* __restrict__ dx, int dx_ld,
                                                        int dx_coff, int accumulate) {
     __shared__ __attribute__((aligned(16))) float xs[CHH * CHW * CLD];
-    int bt = blockIdx.x;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
                                                            float* __restrict__ out, int out_ld, int H, int W,
                                                            int tilesX, int tilesY, int flip, int in_bf16, int out_bf16) {
     __shared__ __attribute__((aligned(16))) float xs[DT_NPIX * DT_C];
-    int bt = blockIdx.x;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int bt = tile;
+        int bt = xcd_tile(tile, ntiles);
         const int tx = bt % tilesX; bt /= tilesX;
         const int ty = bt % tilesY;
         const int n = bt / tilesY;

@@ -53,6 +53,10 @@ class Geometry:
         self.NI = self.T * self.B
         self.NO = (self.T - 1) * self.B
         self.CAT = F + GROWTH * LAYERS
+        # Pixel stride of the dense-block buffers: a multiple of 64 channels, so that every pixel of the bf16 buffer
+        # starts on a 128-B line (F=64: 224 -> 256).  The 32-channel (64 B) pieces the conv kernels fetch per pixel
+        # and chunk then never share a line with the neighbouring pixel: measured 171 -> 146 us on the cin=192 conv.
+        self.CATLD = (self.CAT + 63) // 64 * 64
         self.Tp = K.pad4(self.T)
         self.U = self.Cimg * scale * scale
         self.Up = K.pad4(self.U)
@@ -158,7 +162,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     K.cbam_channel(gap_partial, nblk, F, g.R, B, H * W, w1, w2, gap, hid, ca)
     sm, amax, sa = _new(dev, B, H, W, 2), _new(dev, B, H, W, dtype=torch.int32), _new(dev, B, H, W)
     K.cbam_pool(weighted, ca, sm, amax)
-    cats = [_new(dev, B, H, W, g.CAT, dtype=act_dtype) for _ in range(nblocks)]
+    cats = [_new(dev, B, H, W, g.CATLD, dtype=act_dtype) for _ in range(nblocks)]
     resout = _new(dev, B, H, W, F)
 
     def xloc(k):  # where the input of block k / the output of block k-1 lives
@@ -177,7 +181,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
                            Sl(cat, GROWTH, cin), 3, relu=True, math=math)
         wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
-        K.conv_forward(Sl(cat), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
+        K.conv_forward(Sl(cat, g.CAT, 0), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
                        res=Sl(cat, F, 0), math=math)
 
     # ---- global fusion + upsampler tail
@@ -222,7 +226,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
     # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
-    dcats = [_new(dev, B, H, W, g.CAT, dtype=act_dtype), _new(dev, B, H, W, g.CAT, dtype=act_dtype)] if nb else []
+    dcats = [_new(dev, B, H, W, g.CATLD, dtype=act_dtype), _new(dev, B, H, W, g.CATLD, dtype=act_dtype)] if nb else []
     dagg = _new(dev, B, H, W, F)
     gout = Sl(dcats[(nb - 1) & 1], F, 0) if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
@@ -235,7 +239,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
         gout = Sl(dcat, F, 0)
-        _wgrad(Sl(cat), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
+        _wgrad(Sl(cat, g.CAT, 0), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
         wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
@@ -246,7 +250,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
         nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
-        K.conv_forward(Sl(dcat), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
+        K.conv_forward(Sl(dcat, g.CAT, 0), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
     dprev = Sl(dagg)
 
     _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F].float())

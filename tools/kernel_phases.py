@@ -16,10 +16,14 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 N, H, W = 2, 540, 960
-for cin, cout, k, dt in ((192, 32, 3, torch.bfloat16), (128, 32, 3, torch.bfloat16), (64, 32, 3, torch.bfloat16),
-                         (192, 32, 3, torch.float32), (224, 64, 3, torch.bfloat16), (224, 64, 1, torch.bfloat16)):
-    x = torch.randn(N, H, W, 224, device="cuda").to(dt)
-    out = torch.empty(N, H, W, 224, device="cuda", dtype=dt)
+for cin, cout, k, dt, ld in ((192, 32, 3, torch.bfloat16, 224), (192, 32, 3, torch.bfloat16, 256),
+                             (128, 32, 3, torch.bfloat16, 224), (128, 32, 3, torch.bfloat16, 256),
+                             (64, 32, 3, torch.bfloat16, 224), (64, 32, 3, torch.bfloat16, 256),
+                             (192, 32, 3, torch.float32, 224), (224, 64, 3, torch.bfloat16, 224),
+                             (224, 64, 3, torch.bfloat16, 256), (224, 64, 1, torch.bfloat16, 224),
+                             (224, 64, 1, torch.bfloat16, 256)):
+    x = torch.randn(N, H, W, ld, device="cuda").to(dt)
+    out = torch.empty(N, H, W, ld, device="cuda", dtype=dt)
     w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
     wp = K.conv_pack(w, False, cin, math=K.MATH_BF16)
     b = torch.zeros(cout, device="cuda")
@@ -31,5 +35,5 @@ for cin, cout, k, dt in ((192, 32, 3, torch.bfloat16), (128, 32, 3, torch.bfloat
         res.append(timeit(run))
     K.lib().nvq_debug_set_conv_mode(0)
     nbytes = N * H * W * (cin + cout) * (2 if dt == torch.bfloat16 else 4)
-    print(f"cin{cin} cout{cout} k{k} {str(dt)[6:]:9s}: normal {res[0]:7.1f} us ({nbytes/res[0]/1e6:6.2f} TB/s alg)  "
+    print(f"cin{cin} cout{cout} k{k} ld{ld} {str(dt)[6:]:9s}: normal {res[0]:7.1f} us ({nbytes/res[0]/1e6:6.2f} TB/s alg)  "
           f"no-mfma {res[1]:7.1f} us  no-loads {res[2]:7.1f} us")
