@@ -8,49 +8,92 @@ namespace nvq {
 struct SlotMap { int t[NVQ_MAX_T]; };
 
 // ---------------------------------------------------------------- head conv (NCHW image -> NHWC features)
+// Work item = one row segment of HEAD_SEG pixels x 4 output channels.  A thread walks its segment with a 3-column
+// window of the CIN x 3 input rows in registers (CIN*3 image loads per pixel instead of CIN*9, each a broadcast to the
+// F/4 lanes of the pixel) and keeps its 4 x CIN*9 weights in registers for the whole (persistent) launch.
+constexpr int HEAD_SEG = 32;
+
+template <int CIN>
+struct HeadWindow {
+    const float* row[CIN][3];   // row pointers (clamped); rv = row inside the image
+    bool rv[3];
+    float v[CIN][3][3];
+    int W;
+    __device__ __forceinline__ void open(const float* img, int H, int W_, int y) {
+        W = W_;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            rv[dy] = yy >= 0 && yy < H;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) row[ci][dy] = img + ((size_t)ci * H + (rv[dy] ? yy : 0)) * W;
+        }
+    }
+    __device__ __forceinline__ void load_col(int slot, int xx) {      // column xx of the window into slot
+        const bool ok = xx >= 0 && xx < W;
+        const int xc = ok ? xx : 0;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float t = row[ci][dy][xc];
+                v[ci][dy][slot] = (ok && rv[dy]) ? t : 0.f;
+            }
+    }
+    __device__ __forceinline__ void shift() {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) { v[ci][dy][0] = v[ci][dy][1]; v[ci][dy][1] = v[ci][dy][2]; }
+    }
+};
+
 template <int CIN>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ frames, int B, int T,
                                                        int H, int W, SlotMap sm,
                                                        const float* __restrict__ weight,
                                                        const float* __restrict__ bias, int F,
-                                                       float* __restrict__ out, int out_ld,
-                                                       long total) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [CIN*9][F] then bias[F]
-    const int K = CIN * 9;
-    for (int i = threadIdx.x; i < K * F; i += 256) {
-        const int co = i % F, k = i / F;
-        wl[i] = weight[co * K + k];
-    }
-    for (int i = threadIdx.x; i < F; i += 256) wl[K * F + i] = bias[i];
-    __syncthreads();
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= total) return;
+                                                       float* __restrict__ out, int out_ld, long nseg, int segsX) {
+    constexpr int K = CIN * 9;
     const int F4 = F >> 2;
-    const int c4 = gid % F4;
-    const long pixlin = gid / F4;
-    const int x = pixlin % W;
-    const int y = (pixlin / W) % H;
-    const int n = pixlin / ((long)W * H);
-    const int slot = n / B, b = n - slot * B;
-    const float* img = frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W;
-    float4 acc = ld4(wl + K * F + 4 * c4);
+    const int npl = 256 / F4;
+    const int c4 = threadIdx.x % F4;
+    const int pl = threadIdx.x / F4;
+    float4 w[K];
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
+    for (int k = 0; k < K; ++k)
+        w[k] = make_float4(weight[(4 * c4 + 0) * K + k], weight[(4 * c4 + 1) * K + k], weight[(4 * c4 + 2) * K + k],
+                           weight[(4 * c4 + 3) * K + k]);
+    const float4 bv = ld4(bias + 4 * c4);
+    HeadWindow<CIN> win;
+    for (long item = (long)blockIdx.x * npl + pl; item < nseg; item += (long)gridDim.x * npl) {
+        const int xs = item % segsX;
+        const int y = (item / segsX) % H;
+        const int n = item / ((long)segsX * H);
+        const int slot = n / B, b = n - slot * B;
+        win.open(frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W, H, W, y);
+        const int x0 = xs * HEAD_SEG, x1 = min(x0 + HEAD_SEG, W);
+        win.load_col(0, x0 - 1);
+        win.load_col(1, x0);
+        float* orow = out + ((size_t)(n * H + y) * W) * out_ld + 4 * c4;
+        for (int x = x0; x < x1; ++x) {
+            win.load_col(2, x + 1);
+            float4 acc = bv;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + dy - 1;
+            for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xx = x + dx - 1;
-                float v = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((size_t)ci * H + yy) * W + xx];
-                const float4 w = ld4(wl + (ci * 9 + dy * 3 + dx) * F + 4 * c4);
-                acc.x += v * w.x; acc.y += v * w.y; acc.z += v * w.z; acc.w += v * w.w;
-            }
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = win.v[ci][dy][dx];
+                        const float4 wk = w[ci * 9 + dy * 3 + dx];
+                        acc.x += v * wk.x; acc.y += v * wk.y; acc.z += v * wk.z; acc.w += v * wk.w;
+                    }
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            st4(orow + (size_t)x * out_ld, acc);
+            win.shift();
         }
     }
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    st4(out + pixlin * out_ld + 4 * c4, acc);
 }
 
 // Cross pixel-lane reduction of a float4 inside a 256-thread block whose threads are laid out
@@ -69,13 +112,13 @@ __device__ __forceinline__ float4 plane_reduce4(float4 v, float4* buf, int C4, i
     return s;
 }
 
-// dW[co][ci][tap], db[co] partials: part[blk][F*CIN*9 + F]
+// dW[co][ci][tap], db[co] partials: part[blk][F*CIN*9 + F]; same segment walk as head_fwd_kernel
 template <int CIN>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ frames, int B, int T,
                                                          int H, int W, SlotMap sm,
                                                          const float* __restrict__ dout, int dout_ld,
                                                          const float* __restrict__ act, int act_ld,
-                                                         int F, long npix, float* __restrict__ part) {
+                                                         int F, long nseg, int segsX, float* __restrict__ part) {
     __shared__ float4 buf[256];
     constexpr int K = CIN * 9;
     const int F4 = F >> 2;
@@ -85,33 +128,42 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     float4 acc[K + 1];
 #pragma unroll
     for (int k = 0; k <= K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
-        const int x = p % W;
-        const int y = (p / W) % H;
-        const int n = p / ((long)W * H);
+    HeadWindow<CIN> win;
+    for (long item = (long)blockIdx.x * npl + pl; item < nseg; item += (long)gridDim.x * npl) {
+        const int xs = item % segsX;
+        const int y = (item / segsX) % H;
+        const int n = item / ((long)segsX * H);
         const int slot = n / B, b = n - slot * B;
-        const float* img = frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W;
-        float4 g = ld4(dout + p * dout_ld + 4 * c4);
-        const float4 a = ld4(act + p * act_ld + 4 * c4);
-        if (!(a.x > 0.f)) g.x = 0.f;
-        if (!(a.y > 0.f)) g.y = 0.f;
-        if (!(a.z > 0.f)) g.z = 0.f;
-        if (!(a.w > 0.f)) g.w = 0.f;
-        acc[K].x += g.x; acc[K].y += g.y; acc[K].z += g.z; acc[K].w += g.w;
+        win.open(frames + ((size_t)(b * T + sm.t[slot]) * CIN) * H * W, H, W, y);
+        const int x0 = xs * HEAD_SEG, x1 = min(x0 + HEAD_SEG, W);
+        win.load_col(0, x0 - 1);
+        win.load_col(1, x0);
+        const size_t prow0 = (size_t)(n * H + y) * W;
+        float4 g = ld4(dout + (prow0 + x0) * dout_ld + 4 * c4);
+        float4 a = ld4(act + (prow0 + x0) * act_ld + 4 * c4);
+        for (int x = x0; x < x1; ++x) {
+            win.load_col(2, x + 1);
+            const int xn = x + 1 < x1 ? x + 1 : x;              // next pixel's gradient / activation, one ahead
+            const float4 gn = ld4(dout + (prow0 + xn) * dout_ld + 4 * c4);
+            const float4 an = ld4(act + (prow0 + xn) * act_ld + 4 * c4);
+            if (!(a.x > 0.f)) g.x = 0.f;
+            if (!(a.y > 0.f)) g.y = 0.f;
+            if (!(a.z > 0.f)) g.z = 0.f;
+            if (!(a.w > 0.f)) g.w = 0.f;
+            acc[K].x += g.x; acc[K].y += g.y; acc[K].z += g.z; acc[K].w += g.w;
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
+            for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = y + dy - 1;
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int xx = x + dx - 1;
-                    float v = 0.f;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((size_t)ci * H + yy) * W + xx];
-                    float4& s = acc[ci * 9 + dy * 3 + dx];
-                    s.x += v * g.x; s.y += v * g.y; s.z += v * g.z; s.w += v * g.w;
-                }
-            }
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = win.v[ci][dy][dx];
+                        float4& s = acc[ci * 9 + dy * 3 + dx];
+                        s.x += v * g.x; s.y += v * g.y; s.z += v * g.z; s.w += v * g.w;
+                    }
+            g = gn; a = an;
+            win.shift();
+        }
     }
     float* prow = part + (size_t)blockIdx.x * (F * K + F);
 #pragma unroll
@@ -613,17 +665,20 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots, const float* weight, const float* bias,
                      int F, float* out, int out_ld, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_forward: in_channels %d not supported (1 or 3)", Cin);
-    NVQ_REQUIRE(F % 4 == 0 && F <= 256 && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d / ld %d", F, out_ld);
+    NVQ_REQUIRE(pow2_c4(F) && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d (power of two in [4,256]) / ld %d", F, out_ld);
     NVQ_REQUIRE(nslots >= 1 && nslots <= NVQ_MAX_T && T <= NVQ_MAX_T, "head_forward: T %d slots %d", T, nslots);
     SlotMap sm;
     for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
-    const long total = (long)nslots * B * H * W * (F / 4);
-    const size_t shm = (size_t)(Cin * 9 * F + F) * sizeof(float);
+    const int segsX = (W + HEAD_SEG - 1) / HEAD_SEG;
+    const long nseg = (long)nslots * B * H * segsX;
+    const int npl = 256 / (F / 4);
+    int nblk = ceil_div(nseg, npl);
+    if (nblk > 2048) nblk = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 3)
-        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(ceil_div(total, 256)), dim3(256), shm, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, total);
+        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, nseg, segsX);
     else
-        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(ceil_div(total, 256)), dim3(256), shm, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, total);
+        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, nseg, segsX);
     return check_launch("head_forward");
 }
 
@@ -636,17 +691,18 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     NVQ_REQUIRE(dout_ld % 4 == 0 && act_ld % 4 == 0, "head_wgrad: ld");
     SlotMap sm;
     for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
-    const long npix = (long)nslots * B * H * W;
     const int K = Cin * 9;
-    int nblk = blocks_for(npix, F);
+    const int segsX = (W + HEAD_SEG - 1) / HEAD_SEG;
+    const long nseg = (long)nslots * B * H * segsX;
+    int nblk = ceil_div(nseg, 256 / (F / 4));
     if (nblk > 1024) nblk = 1024;       // 4 workgroups per CU: the 112 accumulators per thread need the latency cover
     const size_t row = (size_t)F * K + F;
     if (row * nblk * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 3)
-        hipLaunchKernelGGL((head_wgrad_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, npix, workspace);
+        hipLaunchKernelGGL((head_wgrad_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace);
     else
-        hipLaunchKernelGGL((head_wgrad_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, npix, workspace);
+        hipLaunchKernelGGL((head_wgrad_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace);
     int rc = check_launch("head_wgrad");
     if (rc) return rc;
     // rows are [F*K weights | F biases]; reduce the two pieces separately (row stride = row)
