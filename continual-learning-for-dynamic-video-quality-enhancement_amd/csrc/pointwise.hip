@@ -407,6 +407,166 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------- depthwise 3x3, bf16 input, 64-channel tiles
+// Same tile walk as above for bf16-stored inputs with C % 64 == 0: the workgroup takes 64 channels, i.e. the whole
+// 128-B line of a pixel (the 32-channel tiles split every line between two workgroups), the halo tile sits in LDS as
+// bf16 [340 px][64 ch]; 512 threads, thread (c4 = tid & 15, x = tid >> 4) owns 4 channels of its column.
+constexpr int DB_C = 64, DB_T = 512;
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dw_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float4 dw_unpack4(dw_u32x2 v) {
+    return make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                       __uint_as_float(v[1] & 0xffff0000u));
+}
+
+__device__ __forceinline__ void dw_stage_halo_bf16(const __bf16* __restrict__ in, int in_ld, int n, int H, int W, int ty0,
+                                                   int tx0, int ch0, __bf16* xs) {
+    constexpr int PER = (DT_NPIX * 8 + DB_T - 1) / DB_T;
+    dw_u32x4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                      // all loads first (clamped addresses), then the stores
+        const int item = threadIdx.x + k * DB_T;
+        const int hp = item >> 3, q = item & 7;
+        const int hy = hp / DT_HW, hx = hp - hy * DT_HW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool ok = item < DT_NPIX * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t idx = ok ? ((size_t)(n * H + gy) * W + gx) * in_ld + ch0 + 8 * q : 0;
+        v[k] = *reinterpret_cast<const dw_u32x4*>(in + idx);
+        if (!ok) v[k] = (dw_u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int item = threadIdx.x + k * DB_T;
+        if (item < DT_NPIX * 8) *reinterpret_cast<dw_u32x4*>(xs + (item >> 3) * DB_C + 8 * (item & 7)) = v[k];
+    }
+}
+
+__device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
+    return dw_unpack4(*reinterpret_cast<const dw_u32x2*>(xs + hp * DB_C + 4 * c4));
+}
+
+// grid (tiles, C/64)
+__global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
+                                                           const float* __restrict__ weight, int C,
+                                                           float* __restrict__ out, int out_ld, int H, int W, int tilesX,
+                                                           int tilesY, int flip, int out_bf16) {
+    __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int ch0 = blockIdx.y * DB_C;
+    const int c4 = threadIdx.x & 15, x = threadIdx.x >> 4;
+    float4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        const int c = ch0 + 4 * c4;
+        w[t] = make_float4(weight[(c + 0) * 9 + tt], weight[(c + 1) * 9 + tt], weight[(c + 2) * 9 + tt], weight[(c + 3) * 9 + tt]);
+    }
+    dw_stage_halo_bf16(in, in_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+    __syncthreads();
+    const int gx = tx * DT_W + x;
+    float4 r[3][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) r[a][b] = dw_lds4(xs, a * DT_HW + x + b, c4);
+#pragma unroll
+    for (int y = 0; y < DT_H; ++y) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) r[2][b] = dw_lds4(xs, (y + 2) * DT_HW + x + b, c4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float4 v = r[a][b], ww = w[a * 3 + b];
+                acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
+            }
+        const int gy = ty * DT_H + y;
+        if (gy < H && gx < W) stx4(out, ((size_t)(n * H + gy) * W + gx) * out_ld + ch0 + 4 * c4, out_bf16, acc);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+    }
+}
+
+// grid (<= 512 persistent blocks over tiles, C/64): part[blockIdx.x][C*9]; x and dy stored as bf16
+__global__ __launch_bounds__(DB_T) void dwconv_wgrad_bf16_kernel(const __bf16* __restrict__ x, int x_ld,
+                                                                 const __bf16* __restrict__ dy, int dy_ld, int C, int H,
+                                                                 int W, int tilesX, int tilesY, int ntiles,
+                                                                 float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
+    const int ch0 = blockIdx.y * DB_C;
+    const int c4 = threadIdx.x & 15, xx = threadIdx.x >> 4;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int bt = xcd_tile(tile, ntiles);
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
+        const int gx = tx * DT_W + xx;
+        dw_u32x2 g[DT_H];                                 // this thread's dy pieces of the tile, loaded up front
+#pragma unroll
+        for (int y = 0; y < DT_H; ++y) {
+            const int gy = ty * DT_H + y;
+            const bool ok = gy < H && gx < W;
+            g[y] = *reinterpret_cast<const dw_u32x2*>(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * dy_ld + ch0 + 4 * c4 : 0));
+            if (!ok) g[y] = (dw_u32x2){0u, 0u};
+        }
+        __syncthreads();
+        dw_stage_halo_bf16(x, x_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+        __syncthreads();
+        float4 r[3][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[a][b] = dw_lds4(xs, a * DT_HW + xx + b, c4);
+#pragma unroll
+        for (int y = 0; y < DT_H; ++y) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[2][b] = dw_lds4(xs, (y + 2) * DT_HW + xx + b, c4);
+            const float4 gf = dw_unpack4(g[y]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float4 v = r[a][b];
+                    float4& s = acc[a * 3 + b];
+                    s.x += v.x * gf.x; s.y += v.y * gf.y; s.z += v.z * gf.z; s.w += v.w * gf.w;
+                }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+        }
+    }
+    // sum over the 32 x-lanes that share c4: the 4 inside a wave by shuffles, then the 8 waves through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(xs);           // [8 waves][16 c4][36]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += __shfl_xor(v[e], 16, 64);
+            v[e] += __shfl_xor(v[e], 32, 64);
+            if (lane < 16) red[(wave * 16 + lane) * 36 + t * 4 + e] = v[e];
+        }
+    }
+    __syncthreads();
+    float* prow = part + (size_t)blockIdx.x * C * 9;
+    for (int i = threadIdx.x; i < 16 * 36; i += DB_T) {
+        const int ci = i / 36, k = i - ci * 36;           // k = t*4 + e
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) v += red[(wv * 16 + ci) * 36 + k];
+        prow[(ch0 + 4 * ci + (k & 3)) * 9 + (k >> 2)] = v;
+    }
+}
+
 // ---------------------------------------------------------------- BatchNorm
 // grid (blocks per group, G): part[g][blk][2C] = {sum, sum of squares}
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int x_ld, int C,
@@ -721,6 +881,14 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
                        int N, int H, int W, int flip, int in_bf16, int out_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
                 "dwconv_forward: C %d ld %d/%d", C, in_ld, out_ld);
+    if (C % DB_C == 0 && in_bf16) {
+        NVQ_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv_forward(bf16): ld %d/%d must be multiples of 8", in_ld, out_ld);
+        const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
+        hipLaunchKernelGGL(dwconv_bf16_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DB_C), dim3(DB_T), 0,
+                           (hipStream_t)stream, reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W,
+                           tilesX, tilesY, flip, out_bf16);
+        return check_launch("dwconv_bf16");
+    }
     if (C % DT_C == 0) {
         const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
         hipLaunchKernelGGL(dwconv_tiled_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DT_C), dim3(256), 0,
@@ -740,6 +908,18 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
     NVQ_REQUIRE(pow2_c4(C), "dwconv_wgrad: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0, "dwconv_wgrad: ld");
     const long npix = (long)N * H * W;
+    if (C % DB_C == 0 && x_bf16 && dy_bf16 && x_ld % 8 == 0 && dy_ld % 8 == 0) {
+        const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
+        const int ntiles = tilesX * tilesY * N;
+        const int nb = ntiles < 512 ? ntiles : 512;
+        if ((size_t)nb * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
+        hipLaunchKernelGGL(dwconv_wgrad_bf16_kernel, dim3(nb, C / DB_C), dim3(DB_T), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16*>(x), x_ld, reinterpret_cast<const __bf16*>(dy), dy_ld, C, H, W,
+                           tilesX, tilesY, ntiles, workspace);
+        int rc0 = check_launch("dwconv_wgrad_bf16");
+        if (rc0) return rc0;
+        return launch_reduce_partials(workspace, nb, C * 9, 1.f, dweight, accumulate, (hipStream_t)stream);
+    }
     if (C % DT_C == 0) {
         const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
         const int ntiles = tilesX * tilesY * N;

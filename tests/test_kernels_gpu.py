@@ -599,3 +599,25 @@ def test_extractor_kernels_with_bf16_stored_tensors(K):
                        db, ws)
     assert rel(dx.float().permute(0, 3, 1, 2), xg.grad) < 8e-3
     assert rel(dg, gamma.grad) < 5e-5 and rel(db, beta.grad) < 5e-5
+
+
+@pytest.mark.parametrize("C,N,H,W", [(64, 2, 11, 37), (128, 1, 8, 32), (64, 3, 17, 70)])
+def test_dwconv_bf16_full_line_kernels(K, C, N, H, W):
+    """The 64-channel bf16 depthwise kernels (forward, flipped = input gradient, weight gradient), ragged tiles,
+    fp32 and bf16 outputs."""
+    x = bf(rnd(N, C, H, W) * 1.5 + 0.3)
+    w = rnd(C, 1, 3, 3)
+    ref = F.conv2d(x, w, None, padding=1, groups=C)
+    for odt, tol in ((torch.float32, TOL), (torch.bfloat16, 5e-3)):
+        out = torch.empty(N, H, W, C, device="cuda", dtype=odt)
+        K.dwconv_forward(to_nhwc_bf16(x), w.cuda(), out)
+        assert rel(out.float().permute(0, 3, 1, 2), ref) < tol
+    dy = bf(rnd(N, C, H, W, seed=6))
+    xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+    F.conv2d(xg, wg, None, padding=1, groups=C).backward(dy)
+    dx = torch.empty(N, H, W, C, device="cuda")
+    K.dwconv_forward(to_nhwc_bf16(dy), w.cuda(), dx, flip=True)
+    assert rel(dx.permute(0, 3, 1, 2), xg.grad) < TOL
+    dw = torch.empty(C, 1, 3, 3, device="cuda")
+    K.dwconv_wgrad(to_nhwc_bf16(x), to_nhwc_bf16(dy), dw, ws_tensor(K))
+    assert rel(dw, wg.grad) < TOL
