@@ -1,0 +1,298 @@
+// 9x9 local correlation on the matrix cores (NVQ_MATH_BF16): forward and both gradients.
+//
+// For a block of 16 pixels P of one image row and one displacement row i, the 16 x 9 products
+//   corr[p, i*9 + j] = (1/C) x1[p] . x2[(y+i-4, x_p+j-4)]
+// are the band 0 <= q-p <= 8 of the 16 x 24 matrix  S = X1[P] . X2row[Q]^T  (Q = the 24 halo pixels of row y+i-4):
+// one 16x16x32 bf16 MFMA per 16 q and 32 channels.  Only 28 % of S is used, but the whole correlation is 43 GFLOP
+// per pass at 540p x 8 images - on the matrix cores that is noise, while the per-pixel fp32 loop of motion.hip is
+// bound by its LDS reads (324 ds_read_b128 per pixel and 16 channels).  The gradients are the same band turned into a
+// GEMM operand:  dX[P] (+)= Band_i . Yrow[Q]  with K = q.
+//
+// Workgroup = 8 rows x 16 pixels, 8 waves, wave w = tile row w.  The 16 x 24-pixel halo of the "other" tensor sits in
+// LDS as bf16 [384 px][C + 16]: the +16 halfs (pixel stride 160 B at C = 64, 96 B at C = 32) make the b128 row reads of
+// the forward conflict-free.  fp32 inputs are rounded to bf16 when staged; accumulation is fp32.
+#include "common.h"
+
+namespace nvq {
+
+constexpr int MT_H = 8, MT_W = 16;              // pixel tile
+constexpr int MD = 4, MN = 9, MND = 81;         // displacement radius, row length, count
+constexpr int MHH = MT_H + 2 * MD;              // 16 halo rows
+constexpr int MHW = MT_W + 2 * MD;              // 24 halo columns
+constexpr int MHP = MHH * MHW;                  // 384 halo pixels
+constexpr int M_T = 512;                        // threads
+constexpr int M_DSTR = 104;                     // halfs per pixel of a staged dcorr row (96 used; 208 B keeps 16-B pieces aligned)
+constexpr int M_OSTR = 84;                      // floats per pixel of the forward's output staging rows
+
+typedef unsigned m_u32x4 __attribute__((ext_vector_type(4)));
+typedef short m_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ m_u32x4 cvt_f8_bf16(float4 a, float4 b) {
+    return (m_u32x4){pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+}
+
+// Stage the halo of fp32 `src` image `n` (C channels from src, origin (ty0-4, tx0-4)) as bf16 [384][C+16].
+template <int C>
+__device__ __forceinline__ void m_stage_halo(const float* __restrict__ src, int ld, int n, int H, int W, int ty0, int tx0,
+                                             __bf16* ys) {
+    constexpr int YS = C + 16;
+    constexpr int PPP = C / 8;                   // 16-byte bf16 pieces per pixel
+    constexpr int ITEMS = MHP * PPP;
+    constexpr int PER = ITEMS / M_T;             // exact: 384 * {4, 8} / 512
+    static_assert(ITEMS % M_T == 0, "halo pieces must divide evenly");
+    float4 a[PER], b[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {              // loads first (clamped addresses), conversion + stores after
+        const int item = threadIdx.x + k * M_T;
+        const int hp = item / PPP, q = item - hp * PPP;
+        const int hy = hp / MHW, hx = hp - hy * MHW;
+        const int gy = ty0 + hy - MD, gx = tx0 + hx - MD;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float* p = src + (ok ? ((size_t)(n * H + gy) * W + gx) * ld + 8 * q : 0);
+        a[k] = ld4(p);
+        b[k] = ld4(p + 4);
+        if (!ok) { a[k] = make_float4(0.f, 0.f, 0.f, 0.f); b[k] = a[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int item = threadIdx.x + k * M_T;
+        const int hp = item / PPP, q = item - hp * PPP;
+        *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = cvt_f8_bf16(a[k], b[k]);
+    }
+}
+
+// ---------------------------------------------------------------- forward
+// out[n,p,i*9+j] = (1/C) sum_c x1[n,p,c] * x2[n % x2_images, p + (i-4, j-4), c]; channels 81..out_ld-1 zeroed.
+template <int C, bool OUT_BF16>
+__global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restrict__ x1, int x1_ld,
+                                                            const float* __restrict__ x2, int x2_ld, int x2_images, int H,
+                                                            int W, int tilesX, int tilesY, float* __restrict__ out,
+                                                            int out_ld) {
+    constexpr int YS = C + 16;
+    constexpr int KS = C / 32;                   // MFMA k-steps
+    __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
+    __shared__ __attribute__((aligned(16))) float stage[MT_H * MT_W * M_OSTR];
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int gy = ty * MT_H + r, gx = tx * MT_W + p;
+    const bool inside = gy < H && gx < W;
+
+    // this lane's x1 operand: pixel p of row r, channels 32s + 8g .. +7   (B: k = channel, n = pixel)
+    bf16x8 xb[KS];
+    {
+        const float* src = x1 + (inside ? ((size_t)(n * H + gy) * W + gx) * x1_ld : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float4 a = ld4(src + 32 * s + 8 * g), b = ld4(src + 32 * s + 8 * g + 4);
+            if (!inside) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+            xb[s] = __builtin_bit_cast(bf16x8, cvt_f8_bf16(a, b));
+        }
+    }
+    m_stage_halo<C>(x2, x2_ld, n % x2_images, H, W, ty * MT_H, tx * MT_W, ys);
+    float* srow = stage + (r * MT_W) * M_OSTR;
+    if (lane < 16) { srow[lane * M_OSTR + 81] = 0.f; srow[lane * M_OSTR + 82] = 0.f; srow[lane * M_OSTR + 83] = 0.f; }
+    __syncthreads();
+
+    const float inv = 1.f / (float)C;
+#pragma unroll 1
+    for (int i = 0; i < MN; ++i) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // A: m = halo pixel qb*8 + (lane & 15) of halo row r + i, k = channel
+            const __bf16* arow = ys + ((r + i) * MHW + qb * 8 + p) * YS + 8 * g;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + 32 * s), xb[s], acc, 0,
+                                                              0, 0);
+            // D[m = 4g + e][n = p]: halo column q = qb*8 + 4g + e, displacement j = q - p.
+            // qb = 0 serves q <= 15, qb = 1 the columns 16..23 (its m >= 8); both only inside the band 0 <= j <= 8.
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * g + e;
+                const int j = qb * 8 + m - p;
+                if (j >= 0 && j <= 8 && (qb == 0 || m >= 8)) srow[p * M_OSTR + i * MN + j] = acc[e] * inv;
+            }
+        }
+    }
+    __syncthreads();
+    // row r of the tile: 16 pixels x out_ld channels, written as whole 16-byte pieces
+    if (gy >= H) return;
+    if constexpr (OUT_BF16) {
+        __bf16* o16 = reinterpret_cast<__bf16*>(out);
+        const int ppp = out_ld / 8;              // pieces per pixel (out_ld % 8 == 0 checked on the host)
+        for (int item = lane; item < MT_W * ppp; item += 64) {
+            const int px = item / ppp, q = item - px * ppp;
+            if (tx * MT_W + px >= W) continue;
+            m_u32x4 v = {0u, 0u, 0u, 0u};
+            if (8 * q < M_OSTR) {
+                const float4 a = ld4(srow + px * M_OSTR + 8 * q);
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (8 * q + 4 < M_OSTR) b = ld4(srow + px * M_OSTR + 8 * q + 4);
+                v = cvt_f8_bf16(a, b);
+            }
+            *reinterpret_cast<m_u32x4*>(o16 + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 8 * q) = v;
+        }
+    } else {
+        const int ppp = out_ld / 4;
+        for (int item = lane; item < MT_W * ppp; item += 64) {
+            const int px = item / ppp, q = item - px * ppp;
+            if (tx * MT_W + px >= W) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * q < M_OSTR) v = ld4(srow + px * M_OSTR + 4 * q);
+            st4(out + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 4 * q, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- gradients
+// WHICH == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d]          * other[n % oi, p + off(d), c]
+// WHICH == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q - off(d),d] * other[n,      q - off(d), c]
+// Both are  D[c][p] = sum_{q'} Y[(r+i, q')][c] * B_i[q'][p]  over the 24 (padded to 32) halo columns q' of halo row r+i:
+//   WHICH 1: B_i[q'][p] = dcorr[p, i*9 + (q'-p)]                                   (dcorr of the tile's own pixels)
+//   WHICH 2: B_i[q'][p] = dcorr[(r+i, q'), (8-i)*9 + 8 - (q'-p)]                   (dcorr of the halo pixel itself)
+// inside the band 0 <= q'-p <= 8, zero outside.  A (m = channel, k = q') comes from the [pixel][channel] halo image by
+// ds_read_b64_tr_b16; B is gathered element-wise (8 bf16 per lane) from the staged dcorr rows.
+template <int C, int WHICH, bool D_BF16>
+__global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restrict__ dcorr, int dcorr_ld,
+                                                            const float* __restrict__ other, int other_ld,
+                                                            int other_images, int H, int W, int tilesX, int tilesY,
+                                                            float* __restrict__ dx, int dx_ld, int dx_coff,
+                                                            int accumulate) {
+    constexpr int YS = C + 16;
+    constexpr int NCB = C / 16;
+    constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
+    __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
+    __shared__ __attribute__((aligned(16))) __bf16 ds[DPX * M_DSTR];
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+
+    // ---- stage dcorr (channels 0..95 of each pixel; 12 pieces of 8)
+    {
+        constexpr int ITEMS = DPX * 12;
+        constexpr int PER = (ITEMS + M_T - 1) / M_T;
+        const __bf16* d16 = reinterpret_cast<const __bf16*>(dcorr);
+#pragma unroll 3
+        for (int k = 0; k < PER; ++k) {
+            const int item = threadIdx.x + k * M_T;
+            if (item >= ITEMS) break;
+            const int dp = item / 12, q = item - dp * 12;
+            int gy, gx;
+            if (WHICH == 1) { gy = ty * MT_H + dp / MT_W; gx = tx * MT_W + dp % MT_W; }
+            else { gy = ty * MT_H + dp / MHW - MD; gx = tx * MT_W + dp % MHW - MD; }
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            m_u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const size_t idx = ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q;
+                if constexpr (D_BF16) v = *reinterpret_cast<const m_u32x4*>(d16 + idx);
+                else v = cvt_f8_bf16(ld4(dcorr + idx), ld4(dcorr + idx + 4));
+            }
+            *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = v;
+        }
+    }
+    m_stage_halo<C>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys);
+    __syncthreads();
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef m_s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+    const int trq = p >> 2, trp = p & 3;                     // tr-read role inside the 16-lane group
+    const int gq = g < 3 ? g : 2;                            // halo columns 24..31 do not exist; their B rows are zero
+    const unsigned short* dsu = reinterpret_cast<const unsigned short*>(ds);
+#pragma unroll 1
+    for (int i = 0; i < MN; ++i) {
+        // B: n = pixel p, k = halo column q' = 8g + t
+        unsigned bw[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            unsigned half[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = 8 * g + 2 * t2 + h;
+                const int j = q - p;
+                const bool band = j >= 0 && j <= 8;
+                int idx;
+                if (WHICH == 1) idx = (r * MT_W + p) * M_DSTR + i * MN + (band ? j : 0);
+                else idx = ((r + i) * MHW + (band ? q : 0)) * M_DSTR + (8 - i) * MN + (band ? 8 - j : 0);
+                const unsigned v = dsu[idx];
+                half[h] = band ? v : 0u;
+            }
+            bw[t2] = half[0] | (half[1] << 16);
+        }
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, (m_u32x4){bw[0], bw[1], bw[2], bw[3]});
+        const __bf16* yrow = ys + ((r + i) * MHW + 8 * gq + trq) * YS + 4 * trp;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            // A: m = channel cb*16 + (lane & 15), k = q' = 8g + e: two transposed 4-pixel x 16-channel reads
+            const m_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + cb * 16));
+            const m_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + 4 * YS + cb * 16));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfrag, acc[cb], 0, 0, 0);
+        }
+    }
+    // D[m = channel cb*16 + 4g + e][n = pixel p]
+    const int gy = ty * MT_H + r, gx = tx * MT_W + p;
+    if (gy >= H || gx >= W) return;
+    const float inv = 1.f / (float)C;
+    float* op = dx + ((size_t)(n * H + gy) * W + gx) * dx_ld + dx_coff + 4 * g;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
+        if (accumulate) {
+            const float4 o = ld4(op + cb * 16);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        st4(op + cb * 16, v);
+    }
+}
+
+// ---------------------------------------------------------------- host side (called from motion.hip's entry points)
+bool corr_mfma_supported(int C) { return C == 32 || C == 64; }
+
+int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C, int N, int H, int W,
+                      float* out, int out_ld, int out_bf16, hipStream_t s) {
+    NVQ_REQUIRE(out_ld >= 84 && out_ld % (out_bf16 ? 8 : 4) == 0, "correlation_forward(bf16): out_ld %d", out_ld);
+    const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
+    const dim3 grid((unsigned)((long)tilesX * tilesY * N));
+#define NVQ_CF(CC, OB) \
+    hipLaunchKernelGGL((corr_fwd_mfma_kernel<CC, OB>), grid, dim3(M_T), 0, s, x1, x1_ld, x2, x2_ld, x2_images, H, W, tilesX, tilesY, out, out_ld)
+    if (C == 64) { if (out_bf16) NVQ_CF(64, true); else NVQ_CF(64, false); }
+    else { if (out_bf16) NVQ_CF(32, true); else NVQ_CF(32, false); }
+#undef NVQ_CF
+    return check_launch("correlation_forward(bf16)");
+}
+
+int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
+                       int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
+                       hipStream_t s) {
+    NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
+                "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
+    const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
+    const dim3 grid((unsigned)((long)tilesX * tilesY * N));
+#define NVQ_CB(CC, WH, DB) \
+    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate)
+#define NVQ_CB2(CC) \
+    do { if (which == 1) { if (dcorr_bf16) NVQ_CB(CC, 1, true); else NVQ_CB(CC, 1, false); } \
+         else { if (dcorr_bf16) NVQ_CB(CC, 2, true); else NVQ_CB(CC, 2, false); } } while (0)
+    if (C == 64) NVQ_CB2(64); else NVQ_CB2(32);
+#undef NVQ_CB2
+#undef NVQ_CB
+    return check_launch("correlation_backward(bf16)");
+}
+
+}  // namespace nvq

@@ -317,6 +317,14 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// NVQ_MATH_BF16 variants (corr_mfma.hip)
+bool corr_mfma_supported(int C);
+int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C, int N, int H, int W,
+                      float* out, int out_ld, int out_bf16, hipStream_t s);
+int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
+                       int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
+                       hipStream_t s);
+
 }  // namespace nvq
 
 using namespace nvq;
@@ -324,11 +332,14 @@ using namespace nvq;
 extern "C" {
 
 int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C,
-                            int N, int H, int W, float* out, int out_ld, void* stream) {
+                            int N, int H, int W, float* out, int out_ld, int math, int out_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x1_ld % 4 == 0 && x2_ld % 4 == 0 && out_ld % 4 == 0 && out_ld >= 84 &&
                     aligned16(x1) && aligned16(x2) && aligned16(out),
                 "correlation_forward: alignment (C %d out_ld %d)", C, out_ld);
     NVQ_REQUIRE(x2_images > 0, "correlation_forward: x2_images");
+    if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
+        return corr_forward_mfma(x1, x1_ld, x2, x2_ld, x2_images, C, N, H, W, out, out_ld, out_bf16, (hipStream_t)stream);
+    NVQ_REQUIRE(!out_bf16, "correlation_forward: bf16 output needs NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     hipLaunchKernelGGL(corr_fwd_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, (hipStream_t)stream,
                        x1, x1_ld, x2, x2_ld, x2_images, C, H, W, tilesX, tilesY, out, out_ld);
@@ -337,12 +348,16 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
 
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const float* other, int other_ld,
                              int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff,
-                             int accumulate, void* stream) {
+                             int accumulate, int math, int dcorr_bf16, void* stream) {
     NVQ_REQUIRE(which == 1 || which == 2, "correlation_backward: which %d", which);
     NVQ_REQUIRE(C % 4 == 0 && dcorr_ld % 4 == 0 && dcorr_ld >= 84 && other_ld % 4 == 0 && dx_ld % 4 == 0 &&
                     dx_coff % 4 == 0 && aligned16(dcorr) && aligned16(other) && aligned16(dx),
                 "correlation_backward: alignment");
     NVQ_REQUIRE(other_images > 0, "correlation_backward: other_images");
+    if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
+        return corr_backward_mfma(which, dcorr, dcorr_ld, dcorr_bf16, other, other_ld, other_images, C, N, H, W, dx, dx_ld,
+                                  dx_coff, accumulate, (hipStream_t)stream);
+    NVQ_REQUIRE(!dcorr_bf16, "correlation_backward: bf16 dcorr needs NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
     if (which == 1)

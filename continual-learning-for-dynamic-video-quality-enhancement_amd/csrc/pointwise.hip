@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        int H, int W, SlotMap sm,
                                                        const float* __restrict__ weight,
                                                        const float* __restrict__ bias, int F,
-                                                       float* __restrict__ out, int out_ld, long nseg, int segsX) {
+                                                       float* __restrict__ out, int out_ld, int out_bf16,
+                                                       long nseg, int segsX) {
     constexpr int K = CIN * 9;
     const int F4 = F >> 2;
     const int npl = 256 / F4;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         const int x0 = xs * HEAD_SEG, x1 = min(x0 + HEAD_SEG, W);
         win.load_col(0, x0 - 1);
         win.load_col(1, x0);
-        float* orow = out + ((size_t)(n * H + y) * W) * out_ld + 4 * c4;
+        const size_t orow = ((size_t)(n * H + y) * W) * out_ld + 4 * c4;
         for (int x = x0; x < x1; ++x) {
             win.load_col(2, x + 1);
             float4 acc = bv;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                         acc.x += v * wk.x; acc.y += v * wk.y; acc.z += v * wk.z; acc.w += v * wk.w;
                     }
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-            st4(orow + (size_t)x * out_ld, acc);
+            stx4(out, orow + (size_t)x * out_ld, out_bf16, acc);
             win.shift();
         }
     }
@@ -113,7 +114,7 @@ __device__ __forceinline__ float4 plane_reduce4(float4 v, float4* buf, int C4, i
 }
 
 // dW[co][ci][tap], db[co] partials: part[blk][F*CIN*9 + F]; same segment walk as head_fwd_kernel
-template <int CIN>
+template <int CIN, int ACT_BF16>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ frames, int B, int T,
                                                          int H, int W, SlotMap sm,
                                                          const float* __restrict__ dout, int dout_ld,
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
         win.load_col(1, x0);
         const size_t prow0 = (size_t)(n * H + y) * W;
         float4 g = ld4(dout + (prow0 + x0) * dout_ld + 4 * c4);
-        float4 a = ld4(act + (prow0 + x0) * act_ld + 4 * c4);
+        float4 a = ldx4(act, (prow0 + x0) * act_ld + 4 * c4, ACT_BF16);
         for (int x = x0; x < x1; ++x) {
             win.load_col(2, x + 1);
             const int xn = x + 1 < x1 ? x + 1 : x;              // next pixel's gradient / activation, one ahead
             const float4 gn = ld4(dout + (prow0 + xn) * dout_ld + 4 * c4);
-            const float4 an = ld4(act + (prow0 + xn) * act_ld + 4 * c4);
+            const float4 an = ldx4(act, (prow0 + xn) * act_ld + 4 * c4, ACT_BF16);
             if (!(a.x > 0.f)) g.x = 0.f;
             if (!(a.y > 0.f)) g.y = 0.f;
             if (!(a.z > 0.f)) g.z = 0.f;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, int res_ld, float* __restrict__ outA,
     int outA_ld, int outA_coff, int split_images, float* __restrict__ outB, int outB_ld, int outB_coff,
-    int x_bf16, int out_bf16, long total) {
+    int x_bf16, int out_bf16, int res_bf16, long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
     y.z = fmaxf((v.z - m.z) * is.z * ga.z + be.z, 0.f);
     y.w = fmaxf((v.w - m.w) * is.w * ga.w + be.w, 0.f);
     if (res) {
-        const float4 r = ld4(res + pix * res_ld + 4 * c4);
+        const float4 r = ldx4(res, (size_t)pix * res_ld + 4 * c4, res_bf16);
         y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     }
     if (n < split_images)
@@ -823,7 +824,7 @@ extern "C" {
 
 int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots, const float* weight, const float* bias,
-                     int F, float* out, int out_ld, void* stream) {
+                     int F, float* out, int out_ld, int out_bf16, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_forward: in_channels %d not supported (1 or 3)", Cin);
     NVQ_REQUIRE(pow2_c4(F) && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d (power of two in [4,256]) / ld %d", F, out_ld);
     NVQ_REQUIRE(nslots >= 1 && nslots <= NVQ_MAX_T && T <= NVQ_MAX_T, "head_forward: T %d slots %d", T, nslots);
@@ -836,16 +837,16 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
     if (nblk > 2048) nblk = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 3)
-        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, nseg, segsX);
+        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, nseg, segsX);
     else
-        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, nseg, segsX);
+        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, nseg, segsX);
     return check_launch("head_forward");
 }
 
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, const int* t_of_slot_host,
                    int nslots, const float* dout, int dout_ld, const float* act, int act_ld, int F,
                    float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
-                   int accumulate, void* stream) {
+                   int accumulate, int act_bf16, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_wgrad: in_channels %d not supported (1 or 3)", Cin);
     NVQ_REQUIRE(pow2_c4(F), "head_wgrad: F %d must be a power of two in [4,256]", F);
     NVQ_REQUIRE(dout_ld % 4 == 0 && act_ld % 4 == 0, "head_wgrad: ld");
@@ -859,10 +860,11 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     const size_t row = (size_t)F * K + F;
     if (row * nblk * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    if (Cin == 3)
-        hipLaunchKernelGGL((head_wgrad_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace);
-    else
-        hipLaunchKernelGGL((head_wgrad_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace);
+#define NVQ_LAUNCH_HW(CIN, AB) \
+    hipLaunchKernelGGL((head_wgrad_kernel<CIN, AB>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace)
+    if (Cin == 3) { if (act_bf16) NVQ_LAUNCH_HW(3, 1); else NVQ_LAUNCH_HW(3, 0); }
+    else { if (act_bf16) NVQ_LAUNCH_HW(1, 1); else NVQ_LAUNCH_HW(1, 0); }
+#undef NVQ_LAUNCH_HW
     int rc = check_launch("head_wgrad");
     if (rc) return rc;
     // rows are [F*K weights | F biases]; reduce the two pieces separately (row stride = row)
@@ -971,7 +973,7 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res, int res_ld, float* outA, int outA_ld, int outA_coff,
                       int split_images, float* outB, int outB_ld, int outB_coff, int x_bf16, int out_bf16,
-                      void* stream) {
+                      int res_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && outA_ld % 4 == 0 && outA_coff % 4 == 0 && outB_ld % 4 == 0 &&
                     outB_coff % 4 == 0 && (!res || res_ld % 4 == 0),
                 "bn_apply_relu: alignment");
@@ -979,7 +981,7 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
                        C, (long)H * W, group_images, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld,
-                       outA_coff, split_images, outB, outB_ld, outB_coff, x_bf16, out_bf16, total);
+                       outA_coff, split_images, outB, outB_ld, outB_coff, x_bf16, out_bf16, res_bf16, total);
     return check_launch("bn_apply_relu");
 }
 

@@ -87,7 +87,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
 
     # ---- feature extractor, all T frames in one batch (slot order)
-    feat0 = _new(dev, NI, H, W, F)
+    feat0 = _new(dev, NI, H, W, F, dtype=act_dtype)
     K.head_forward(frames, g.slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0)
     aligned = _new(dev, B, H, W, T * F)
     feat_oth = _new(dev, max(NO, 1), H, W, F)
@@ -122,10 +122,12 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
     # ---- motion: correlation -> flow net -> warp, the T-1 reference frames batched
     if NO:
-        corr = _new(dev, NO, H, W, CORR_LD)
-        K.correlation_forward(Sl(feat_oth), center, corr)
+        # bf16 mode: correlation on the matrix cores, stored as bf16 with a 128-channel (256-B) pixel stride
+        corr_bf16 = act_dtype == torch.bfloat16 and F in (32, 64)
+        corr = _new(dev, NO, H, W, 128 if corr_bf16 else CORR_LD, dtype=act_dtype if corr_bf16 else torch.float32)
+        K.correlation_forward(Sl(feat_oth), center, corr, math=math)
         chans = [81, 128, 64, 32, 2]
-        x = Sl(corr)
+        x = Sl(corr, CORR_LD, 0)
         sv.flow_acts = [corr]
         for li, idx in enumerate((0, 2, 4, 6)):
             w = P[f"motion_estimator.flow_net.{idx}.weight"]
@@ -306,10 +308,11 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         for li, idx in reversed(list(enumerate((0, 2, 4, 6)))):
             x_t = acts[li]
             name = f"motion_estimator.flow_net.{idx}."
-            _wgrad(Sl(x_t), chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
+            x_sl = Sl(x_t) if li > 0 else Sl(x_t, CORR_LD, 0)
+            _wgrad(x_sl, chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
             cin_store = dy_t.shape[-1]
             wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li], math=math)
-            dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else torch.float32)
+            dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else x_t.dtype)
             if li > 0:
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
                                mask_c1=chans[li], math=math)
@@ -321,10 +324,10 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         _capture("dflow", dflow)
         _capture("dcorr", dcorr)
         center = Sl(sv.aligned, F, c * F)
-        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True)
+        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math)
         for j in range(1, T):
             lo, hi = (j - 1) * B, j * B
-            K.correlation_backward(2, dcorr[lo:hi], Sl(sv.feat_oth).images(lo, hi), Sl(dfeat_c), True)
+            K.correlation_backward(2, dcorr[lo:hi], Sl(sv.feat_oth).images(lo, hi), Sl(dfeat_c), True, math=math)
 
     # ---- feature extractor (all frames batched)
     _capture("dfeat_all", dfeat_all)
@@ -364,7 +367,7 @@ def light_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, scale: int, train
     ws = workspace(dev)
     sv = Saved()
     sv.frames, sv.training, sv.math, sv.act_dtype, sv.scale = frames, training, math, act_dtype, scale
-    feat0 = _new(dev, B, H, W, F)
+    feat0 = _new(dev, B, H, W, F, dtype=act_dtype)
     K.head_forward(frames, [0], P["net.0.weight"], P["net.0.bias"], feat0)
     sv.feat0, sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = feat0, [], [], [], [], []
     cur = feat0

@@ -72,16 +72,16 @@ SIGNATURES = {
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
-    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, vp]),
-    "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
     "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp]),
     "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, ci, vp]),
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
-    "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
-    "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
-    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
+    "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
     "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
@@ -338,7 +338,7 @@ def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: 
     B, T, Cin, H, W = frames.shape
     F = weight.shape[0]
     check(lib().nvq_head_forward(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(weight),
-                                 ptr(bias), F, ptr(out), out.shape[-1], stream()), "nvq_head_forward")
+                                 ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), stream()), "nvq_head_forward")
 
 
 def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, dbias, ws, accumulate=False):
@@ -346,7 +346,7 @@ def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, db
     F = dweight.shape[0]
     check(lib().nvq_head_wgrad(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(dout),
                                dout.shape[-1], ptr(act), act.shape[-1], F, ptr(dweight), ptr(dbias), ptr(ws),
-                               ws.numel() * 4, int(accumulate), stream()), "nvq_head_wgrad")
+                               ws.numel() * 4, int(accumulate), is_bf16(act), stream()), "nvq_head_wgrad")
 
 
 def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False):
@@ -384,7 +384,8 @@ def bn_apply_relu(x: torch.Tensor, group_images: int, mean, invstd, gamma, beta,
     check(lib().nvq_bn_apply_relu(ptr(x), ld, Cc, N, group_images, H, W, ptr(mean), ptr(invstd), ptr(gamma),
                                   ptr(beta), ptr(res), res.shape[-1] if res is not None else 0, ptr(outA.t),
                                   outA.ld, outA.coff, split_images, ptr(outB.t) if outB else None,
-                                  outB.ld if outB else 0, outB.coff if outB else 0, is_bf16(x), outA.bf16, stream()),
+                                  outB.ld if outB else 0, outB.coff if outB else 0, is_bf16(x), outA.bf16, is_bf16(res),
+                                  stream()),
           "nvq_bn_apply_relu")
 
 
@@ -400,16 +401,16 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
 
 
 # ----------------------------------------------------------------------------- motion
-def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor):
+def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor, math: int = MATH_F32):
     N, H, W, _ = x1.t.shape
     check(lib().nvq_correlation_forward(x1.base(), x1.ld, x2.base(), x2.ld, x2.n, x1.c, N, H, W, ptr(out),
-                                        out.shape[-1], stream()), "nvq_correlation_forward")
+                                        out.shape[-1], math, is_bf16(out), stream()), "nvq_correlation_forward")
 
 
-def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool):
+def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32):
     N, H, W, ld = dcorr.shape
     check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N, H, W,
-                                         ptr(dx.t), dx.ld, dx.coff, int(accumulate), stream()),
+                                         ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), stream()),
           "nvq_correlation_backward")
 
 

@@ -127,13 +127,13 @@ size_t nvq_sizeof_wgrad_desc(void);
 int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots,
                      const float* weight, const float* bias, int F,
-                     float* out, int out_ld, void* stream);
+                     float* out, int out_ld, int out_bf16, void* stream);
 /* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from dout masked by (act > 0). */
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
                    const int* t_of_slot_host, int nslots,
                    const float* dout, int dout_ld, const float* act, int act_ld, int F,
                    float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
-                   int accumulate, void* stream);
+                   int accumulate, int act_bf16, void* stream);
 
 /* Depthwise 3x3 (groups = C, no bias), efficient_layers.py:38-46.  weight [C][1][3][3].
  * flip == 1 gives the input gradient.  The *_bf16 flags of this section give the storage type of the
@@ -166,7 +166,8 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
                       const float* mean, const float* invstd, const float* gamma,
                       const float* beta, const float* res, int res_ld,
                       float* outA, int outA_ld, int outA_coff, int split_images,
-                      float* outB, int outB_ld, int outB_coff, int x_bf16, int out_bf16, void* stream);
+                      float* outB, int outB_ld, int outB_coff, int x_bf16, int out_bf16, int res_bf16,
+                      void* stream);
 /* Backward of y = relu(bn(x)).  dy is the gradient w.r.t. y; the ReLU mask is recomputed
  * from x and the statistics (gamma*(x-mean)*invstd + beta > 0), so y itself is not needed.
  * training != 0: batch-statistics backward; else running-statistics backward.
@@ -182,20 +183,23 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
  * LiteFlowNetCorrelation(d=4).forward, efficient_layers.py:313-343.
  * out[n,p, i*9+j] = (1/C) sum_c x1[n,p,c] * x2[n, p + (i-4, j-4), c]; channels 81..out_ld-1
  * of each pixel are written as zero.  x2 image index = n % x2_images (centre-frame
- * features are shared by the T-1 reference frames). */
+ * features are shared by the T-1 reference frames).
+ * math == NVQ_MATH_BF16 (and C in {32, 64}): the products run on the bf16 matrix cores (x1 / x2 rounded to bf16,
+ * fp32 accumulation) and out may be stored as bf16 (out_bf16; out_ld then a multiple of 8).  Otherwise exact fp32. */
 int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld,
                             int x2_images, int C, int N, int H, int W,
-                            float* out, int out_ld, void* stream);
+                            float* out, int out_ld, int math, int out_bf16, void* stream);
 /* which == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d] * other[n % other_images, p+off(d), c]
  *             (gradient w.r.t. x1; other = x2)
  * which == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n, q-off(d), c]
  *             (gradient w.r.t. x2 contributed by image n; other = x1, other_images = N;
  *              the caller launches once per reference frame so that the sums into the
- *              shared centre-frame gradient are ordered) */
+ *              shared centre-frame gradient are ordered)
+ * math / dcorr_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96). */
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
                              const float* other, int other_ld, int other_images, int C, int N,
                              int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                             void* stream);
+                             int math, int dcorr_bf16, void* stream);
 
 /* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
  * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2]. */

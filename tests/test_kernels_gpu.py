@@ -188,6 +188,13 @@ def test_head_forward_and_wgrad(K, Fc, B, T, H, W):
     K.head_wgrad(frames.cuda(), slots, to_nhwc(dout.reshape(T * B, Fc, H, W)), out, dw, db, ws_tensor(K))
     assert rel(dw, w.grad) < TOL
     assert rel(db, b.grad) < TOL
+    # bf16-stored head features: same values rounded once; the ReLU mask read from the bf16 tensor is the same mask
+    out16 = torch.empty(T * B, H, W, Fc, device="cuda", dtype=torch.bfloat16)
+    K.head_forward(frames.cuda(), slots, w.detach().cuda(), b.detach().cuda(), out16)
+    assert torch.equal(out16, out.to(torch.bfloat16))
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    K.head_wgrad(frames.cuda(), slots, to_nhwc(dout.reshape(T * B, Fc, H, W)), out16, dw2, db2, ws_tensor(K))
+    assert rel(dw2, w.grad) < TOL and rel(db2, b.grad) < TOL
 
 
 @pytest.mark.parametrize("C,N,H,W", [(32, 2, 9, 14), (64, 1, 7, 33), (16, 3, 5, 5)])
@@ -621,3 +628,35 @@ def test_dwconv_bf16_full_line_kernels(K, C, N, H, W):
     dw = torch.empty(C, 1, 3, 3, device="cuda")
     K.dwconv_wgrad(to_nhwc_bf16(x), to_nhwc_bf16(dy), dw, ws_tensor(K))
     assert rel(dw, wg.grad) < TOL
+
+
+@pytest.mark.parametrize("C,B,R,H,W", [(64, 2, 2, 9, 14), (64, 1, 1, 11, 37), (32, 1, 3, 20, 6), (64, 1, 2, 17, 33)])
+@pytest.mark.parametrize("store_bf16", [False, True])
+def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
+    """NVQ_MATH_BF16 correlation (matrix cores): inputs pre-rounded to bf16 so that only the fp32 summation order
+    differs from the oracle; ragged tiles, shared centre images, fp32- and bf16-stored corr / dcorr."""
+    N = B * R
+    x1 = bf(rnd(N, C, H, W)).requires_grad_()
+    x2 = bf(rnd(B, C, H, W, seed=3)).requires_grad_()
+    out = torch.cat([sr_oracle.correlation(x1[r * B:(r + 1) * B], x2) for r in range(R)], 0)
+    dy = bf(rnd(N, 81, H, W, seed=5))
+    out.backward(dy)
+    x1b = to_nhwc(x1.detach())
+    al = to_nhwc(x2.detach(), 3 * C, C)
+    ld = 128 if store_bf16 else 96
+    corr = torch.full((N, H, W, ld), 3.0, device="cuda", dtype=torch.bfloat16 if store_bf16 else torch.float32)
+    K.correlation_forward(K.Sl(x1b), K.Sl(al, C, C), corr, math=K.MATH_BF16)
+    assert rel(from_nhwc(corr.float(), 81), out.detach()) < (5e-3 if store_bf16 else TOL)
+    assert corr[..., 81:].float().abs().max().item() == 0
+    dcorr = to_nhwc(dy, ld)
+    if store_bf16:
+        dcorr = dcorr.bfloat16()
+    dx1 = to_nhwc(rnd(N, C, H, W, seed=7))
+    base1 = from_nhwc(dx1)
+    K.correlation_backward(1, dcorr, K.Sl(al, C, C), K.Sl(dx1), True, math=K.MATH_BF16)
+    assert rel(from_nhwc(dx1) - base1, x1.grad) < TOL
+    dx2 = torch.zeros(B, H, W, C, device="cuda")
+    for r in range(R):
+        K.correlation_backward(2, dcorr[r * B:(r + 1) * B], K.Sl(x1b).images(r * B, (r + 1) * B), K.Sl(dx2), True,
+                               math=K.MATH_BF16)
+    assert rel(from_nhwc(dx2), x2.grad) < TOL
