@@ -72,19 +72,24 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int cout_w, int ci
 
 // ---------------------------------------------------------------- forward / input gradient
 // INB: the input activation tensor is stored as bf16.
-template <int NB, int KS, bool INB>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc,
-                                                            int vec_ok, int dbg) {
+// NW: waves per workgroup; each wave owns two tile rows, so the tile is 2*NW x 32 pixels.  NW = 8 (16 rows) stages the
+// weight slab once per 512 pixels instead of 256 and carries 19 % halo instead of 33 %: the kernel is bound by its
+// staging side, and for cout <= 32 the slab is as many bytes as the activations of a 256-pixel tile.
+template <int NB, int KS, bool INB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX,
+                                                                               int tilesY, int nkc, int vec_ok, int dbg) {
     constexpr int NT = NB * 16;
+    constexpr int NTHR = 64 * NW;
+    constexpr int TH_ = 2 * NW;
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int HW_ = TW + 2 * HALO;
-    constexpr int HH_ = TH + 2 * HALO;
+    constexpr int HH_ = TH_ + 2 * HALO;
     constexpr int NPIX = HW_ * HH_;
     constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);     // padded slab (see ws_stride_halfs)
     constexpr int XITEMS = NPIX * 4;                          // (pixel, 8-channel group) pieces per chunk
-    constexpr int XPER = (XITEMS + 255) / 256;
-    constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread (exact)
+    constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;
+    constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread of the first 4 waves (exact)
     constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
@@ -119,10 +124,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
     bool xok[XPER];
 #pragma unroll
     for (int k = 0; k < XPER; ++k) {
-        const int item = tid + k * 256;
+        const int item = tid + k * NTHR;
         const int hp = item >> 2;
         const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
+        const int gy = ty * TH_ + hy - HALO, gx = tx * TW + hx - HALO;
         xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld + 8 * (item & 3)) : 0u;
     }
@@ -146,14 +151,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
             }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
+        if (NW == 4 || tid < 256) {                           // wave-uniform: the slab is 256 x WPER pieces
 #pragma unroll
-        for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
+            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
+        }
     };
     auto commit = [&]() {
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
-            const int item = tid + k * 256;
+            const int item = tid + k * NTHR;
             const bool v0 = xok[k] && cv0, v1 = xok[k] && cv1;
             if (item < XITEMS) {
                 __bf16* dst = xs + (item >> 2) * XSB + 8 * (item & 3);
@@ -163,8 +170,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
                     *reinterpret_cast<bf16x8*>(dst) = cvt8(as_f4(v0 ? xr[k][0] : z), as_f4(v1 ? xr[k][XREGS - 1] : z));
             }
         }
+        if (NW == 4 || tid < 256) {
 #pragma unroll
-        for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
+            for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
+        }
     };
 
     fetch(0);
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const nvq_conv_desc d
             }
         }
     }
-    conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok);
+    conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_);
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -442,14 +451,22 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int NT = choose_nt(d.cout);
     const int ncz = (d.cout_store + NT - 1) / NT;
     const int nkc = (d.cin + KCB - 1) / KCB;
-    const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
+    int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
+    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them
+    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && !(g_debug_mode & 4)) {
+        tilesY = (d.h + 2 * TH - 1) / (2 * TH);
+        const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
+                           g_debug_mode & 3);
+        return check_launch("conv_forward_bf16");
+    }
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
 #define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
     do {                                                                                                                 \
         if (d.in_bf16)                                                                                                   \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode);   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);   \
         else                                                                                                             \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode);  \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);  \
     } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);

@@ -45,13 +45,13 @@ __device__ __forceinline__ void wgrad_bias_partial(const nvq_wgrad_desc& d, floa
 // cz*NB*16 + cb*16 + 4g .. +3 of pixel (row = 2*wave + (pb >> 1), x = (pb & 1)*16 + c) of the tile.
 template <int NB>
 __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&acc)[NB][4], int n, int ty, int tx,
-                                              int cz, int wave, int c, int g, int vec_ok) {
+                                              int cz, int wave, int c, int g, int vec_ok, int th = TH) {
     constexpr int NT = NB * 16;
     const int H = d.h, W = d.w;
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
         const int row = 2 * wave + (pb >> 1);
-        const int gy = ty * TH + row;
+        const int gy = ty * th + row;
         const int gx = tx * TW + (pb & 1) * 16 + c;
         if (gy >= H || gx >= W) continue;
         const size_t pix = (size_t)(n * H + gy) * W + gx;

@@ -510,7 +510,8 @@ def to_nhwc_bf16(x, ld=None, coff=0):
 
 
 @pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 13, 37), (224, 64, 1, 1, 11, 40), (192, 32, 3, 1, 8, 35),
-                                              (128, 64, 3, 1, 9, 33), (32, 2, 3, 1, 8, 32)])
+                                              (128, 64, 3, 1, 9, 33), (32, 2, 3, 1, 8, 32),
+                                              (96, 32, 3, 2, 41, 37), (192, 32, 3, 1, 16, 70), (64, 24, 3, 1, 33, 32)])
 def test_conv_bf16_stored_input_and_output(K, cin, cout, k, N, H, W):
     """Input read as stored bf16 (no rounding in the kernel), output written as bf16 (rounded once) or fp32."""
     x, w, b = bf(rnd(N, cin, H, W)), rnd(cout, cin, k, k, scale=0.2), rnd(cout)

@@ -15,13 +15,10 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-N, H, W = 2, 540, 960
-for cin, cout, k, dt, ld in ((192, 32, 3, torch.bfloat16, 224), (192, 32, 3, torch.bfloat16, 256),
-                             (128, 32, 3, torch.bfloat16, 224), (128, 32, 3, torch.bfloat16, 256),
-                             (64, 32, 3, torch.bfloat16, 224), (64, 32, 3, torch.bfloat16, 256),
-                             (192, 32, 3, torch.float32, 224), (224, 64, 3, torch.bfloat16, 224),
-                             (224, 64, 3, torch.bfloat16, 256), (224, 64, 1, torch.bfloat16, 224),
-                             (224, 64, 1, torch.bfloat16, 256)):
+N, H, W = int(os.environ.get("PH_N", 2)), int(os.environ.get("PH_H", 540)), 960
+for cin, cout, k, dt, ld in ((192, 32, 3, torch.bfloat16, 256), (128, 32, 3, torch.bfloat16, 256),
+                             (64, 32, 3, torch.bfloat16, 256), (192, 32, 3, torch.float32, 224),
+                             (224, 64, 3, torch.bfloat16, 256), (224, 64, 1, torch.bfloat16, 256)):
     x = torch.randn(N, H, W, ld, device="cuda").to(dt)
     out = torch.empty(N, H, W, ld, device="cuda", dtype=dt)
     w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
