@@ -129,8 +129,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int gy = ty * TH_ + hy - HALO, gx = tx * TW + hx - HALO;
         xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld + 8 * (item & 3)) : 0u;
+        // out-of-image pieces point at their own channel group of pixel 0 (any readable address; masked at commit)
+        xoff[k] = (xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld) : 0u) + 8 * (item & 3);
     }
+    // Whole halo inside the image and a whole number of chunks: no piece of this tile is ever masked, and the commit can
+    // store the registers as they are (with two waves per SIMD every VALU instruction of the staging code competes with
+    // the other wave's MFMA issue, so the selects are kept out of the common case).
+    const bool interior = ty * TH_ >= HALO && tx * TW >= HALO && ty * TH_ + TH_ + HALO <= H && tx * TW + TW + HALO <= W &&
+                          d.cin % KCB == 0;
     const int chg = 8 * (tid & 3);                            // channel group of this thread's pieces (256 % 4 == 0)
     u32x4 xr[XPER][XREGS];
     u32x4 wr[WPER];
@@ -140,14 +146,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         const int ch = kc * KCB + chg;
         cv0 = ch < d.cin;
         cv1 = ch + 4 < d.cin;
-        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;   // invalid -> element 0 of the slice
+        // a channel group past the slice reads the pixel's group 0 instead (xoff includes + chg, so - chg is in range)
+        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             if constexpr (INB) {
-                xr[k][0] = *reinterpret_cast<const u32x4*>(in16 + xoff[k] + (xok[k] ? o0 : 0));
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in16 + (xoff[k] + o0));
             } else {
-                xr[k][0] = *reinterpret_cast<const u32x4*>(in32 + xoff[k] + (xok[k] ? o0 : 0));
-                xr[k][XREGS - 1] = *reinterpret_cast<const u32x4*>(in32 + xoff[k] + (xok[k] ? o1 : 0));
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in32 + (xoff[k] + o0));
+                xr[k][XREGS - 1] = *reinterpret_cast<const u32x4*>(in32 + (xoff[k] + o1));
             }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
@@ -158,16 +165,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     };
     auto commit = [&]() {
         const u32x4 z = {0u, 0u, 0u, 0u};
+        if (interior) {                                      // workgroup-uniform
 #pragma unroll
-        for (int k = 0; k < XPER; ++k) {
-            const int item = tid + k * NTHR;
-            const bool v0 = xok[k] && cv0, v1 = xok[k] && cv1;
-            if (item < XITEMS) {
-                __bf16* dst = xs + (item >> 2) * XSB + 8 * (item & 3);
-                if constexpr (INB)                           // cin % 8 == 0: a piece is valid or invalid as a whole
-                    *reinterpret_cast<u32x4*>(dst) = v0 ? xr[k][0] : z;
-                else
-                    *reinterpret_cast<bf16x8*>(dst) = cvt8(as_f4(v0 ? xr[k][0] : z), as_f4(v1 ? xr[k][XREGS - 1] : z));
+            for (int k = 0; k < XPER; ++k) {
+                const int item = tid + k * NTHR;
+                if (item < XITEMS) {
+                    __bf16* dst = xs + (item >> 2) * XSB + 8 * (item & 3);
+                    if constexpr (INB) *reinterpret_cast<u32x4*>(dst) = xr[k][0];
+                    else *reinterpret_cast<bf16x8*>(dst) = cvt8(as_f4(xr[k][0]), as_f4(xr[k][XREGS - 1]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XPER; ++k) {
+                const int item = tid + k * NTHR;
+                const bool v0 = xok[k] && cv0, v1 = xok[k] && cv1;
+                if (item < XITEMS) {
+                    __bf16* dst = xs + (item >> 2) * XSB + 8 * (item & 3);
+                    if constexpr (INB)                       // cin % 8 == 0: a piece is valid or invalid as a whole
+                        *reinterpret_cast<u32x4*>(dst) = v0 ? xr[k][0] : z;
+                    else
+                        *reinterpret_cast<bf16x8*>(dst) = cvt8(as_f4(v0 ? xr[k][0] : z), as_f4(v1 ? xr[k][XREGS - 1] : z));
+                }
             }
         }
         if (NW == 4 || tid < 256) {

@@ -661,3 +661,26 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
         K.correlation_backward(2, dcorr[r * B:(r + 1) * B], K.Sl(x1b).images(r * B, (r + 1) * B), K.Sl(dx2), True,
                                math=K.MATH_BF16)
     assert rel(from_nhwc(dx2), x2.grad) < TOL
+
+
+@pytest.mark.parametrize("cin,N,H,W", [(96, 2, 35, 41), (64, 1, 16, 32), (160, 3, 50, 70)])
+def test_conv_bf16_pipelined_kernel_mask_and_bias(K, cin, N, H, W):
+    """The persistent pipelined 3x3 kernel (bf16 input, cout 32, H >= 16): bias + ReLU written in place into the concat
+    buffer, and the mirror-form gradient form (no bias, ReLU mask from a bf16 slice), several tiles per workgroup."""
+    ld = 256
+    cat = bf(rnd(N, ld, H, W))
+    w3, b3 = rnd(32, cin, 3, 3, scale=0.1), rnd(32)
+    catb = to_nhwc_bf16(cat)
+    K.conv_forward(K.Sl(catb, cin, 0), K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16), b3.cuda(), K.Sl(catb, 32, cin), 3,
+                   relu=True, math=K.MATH_BF16)
+    ref3 = F.relu(F.conv2d(cat[:, :cin], bf(w3), b3, padding=1))
+    assert rel(catb[..., cin:cin + 32].float().permute(0, 3, 1, 2), ref3) < 5e-3
+    assert torch.equal(catb[..., :cin].float().cpu(), to_nhwc(cat[:, :cin]).cpu())
+    # gradient form: out = conv(x) masked by (m > 0), fp32 output
+    m = bf(rnd(N, 32, H, W, seed=9))
+    mb = to_nhwc_bf16(m, 64, 32)
+    out = torch.full((N, H, W, 32), 5.0, device="cuda")
+    K.conv_forward(K.Sl(to_nhwc_bf16(cat), cin, 0), K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16), None, K.Sl(out), 3,
+                   mask=K.Sl(mb, 32, 32), mask_c0=0, mask_c1=32, math=K.MATH_BF16)
+    refm = F.conv2d(cat[:, :cin], bf(w3), None, padding=1) * (m > 0)
+    assert rel(from_nhwc(out), refm) < TOL
