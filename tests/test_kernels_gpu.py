@@ -664,9 +664,9 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
 
 
 @pytest.mark.parametrize("cin,N,H,W", [(96, 2, 35, 41), (64, 1, 16, 32), (160, 3, 50, 70)])
-def test_conv_bf16_pipelined_kernel_mask_and_bias(K, cin, N, H, W):
-    """The persistent pipelined 3x3 kernel (bf16 input, cout 32, H >= 16): bias + ReLU written in place into the concat
-    buffer, and the mirror-form gradient form (no bias, ReLU mask from a bf16 slice), several tiles per workgroup."""
+def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
+    """The 16x32-tile 3x3 kernel (bf16 input, cout 32, H >= 16): bias + ReLU written in place into the concat buffer, and
+    the mirror-form gradient form (no bias, ReLU mask from a bf16 slice); interior and border tiles."""
     ld = 256
     cat = bf(rnd(N, ld, H, W))
     w3, b3 = rnd(32, cin, 3, 3, scale=0.1), rnd(32)
