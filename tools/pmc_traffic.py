@@ -1,0 +1,36 @@
+"""Build profiles/<name>_traffic_pmc.json from two rocprofv3 counter-collection csv files (one --pmc FETCH_SIZE pass, one
+--pmc WRITE_SIZE pass of the same bench.py command).  usage: pmc_traffic.py <fetch.csv> <write.csv> <out.json>
+Per-launch HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md (HBM section)."""
+import collections, csv, json, re, sys
+
+LABELS = [(r"conv_bf16_kernel<2, 3", "conv_bf16_kernel<2,3>"), (r"conv_bf16_kernel<4, 3", "conv_bf16_kernel<4,3>"),
+          (r"conv_bf16_kernel<4, 1", "conv_bf16_kernel<4,1>"), (r"wgrad_bf16_kernel<3", "wgrad_bf16_kernel<3>"),
+          (r"wgrad_bf16_kernel<1", "wgrad_bf16_kernel<1>")]
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    names = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for pat, lab in LABELS:
+            if pat in r["Kernel_Name"]:
+                acc[lab].append(float(r["Counter_Value"]))
+                names.setdefault(lab, set()).add(re.sub(r"\(.*", "", r["Kernel_Name"].replace("void nvq::", "")))
+    return acc, names
+
+
+fetch, names = per_kernel(sys.argv[1], "FETCH_SIZE")
+write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --output-format csv -- python3 "
+                  "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer (B=4)",
+       "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 "
+                     "(MI355X_MICROARCH.md, HBM)", "kernels": {}}
+for lab in fetch:
+    f = sum(fetch[lab]) / len(fetch[lab])
+    w = sum(write[lab]) / max(len(write[lab]), 1)
+    out["kernels"][lab] = {"launches": len(fetch[lab]), "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+                           "hbm_bytes_per_launch": (2 * f + w) * 1024, "rocprof_names": sorted(names[lab])}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in out["kernels"].items()}))
