@@ -16,9 +16,10 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 N, H, W = int(os.environ.get("PH_N", 2)), int(os.environ.get("PH_H", 540)), 960
-for cin, cout, k, dt, ld in ((192, 32, 3, torch.bfloat16, 256), (128, 32, 3, torch.bfloat16, 256),
-                             (64, 32, 3, torch.bfloat16, 256), (192, 32, 3, torch.float32, 224),
-                             (224, 64, 3, torch.bfloat16, 256), (224, 64, 1, torch.bfloat16, 256)):
+LDS_ = [int(v) for v in os.environ.get("PH_LD", "256").split(",")]
+for cin, cout, k, dt, ld in [(192, 32, 3, torch.bfloat16, l) for l in LDS_] + [(128, 32, 3, torch.bfloat16, l) for l in LDS_] + [
+                             (64, 32, 3, torch.bfloat16, LDS_[0]), (192, 32, 3, torch.float32, 224),
+                             (224, 64, 3, torch.bfloat16, LDS_[-1]), (224, 64, 1, torch.bfloat16, LDS_[-1])]:
     x = torch.randn(N, H, W, ld, device="cuda").to(dt)
     out = torch.empty(N, H, W, ld, device="cuda", dtype=dt)
     w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
