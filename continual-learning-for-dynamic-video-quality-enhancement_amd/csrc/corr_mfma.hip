@@ -11,17 +11,18 @@
 // Workgroup = 8 rows x 16 pixels, 8 waves, wave w = tile row w.  The 16 x 24-pixel halo of the "other" tensor sits in
 // LDS as bf16 [384 px][C + 16]: the +16 halfs (pixel stride 160 B at C = 64, 96 B at C = 32) make the b128 row reads of
 // the forward conflict-free.  fp32 inputs are rounded to bf16 when staged; accumulation is fp32.
+#include <type_traits>
 #include "common.h"
 
 namespace nvq {
 
 constexpr int MT_H = 8, MT_W = 16;              // pixel tile
-constexpr int MD = 4, MN = 9, MND = 81;         // displacement radius, row length, count
+constexpr int MD = 4, MN = 9;                    // displacement radius, displacements per row
 constexpr int MHH = MT_H + 2 * MD;              // 16 halo rows
 constexpr int MHW = MT_W + 2 * MD;              // 24 halo columns
 constexpr int MHP = MHH * MHW;                  // 384 halo pixels
 constexpr int M_T = 512;                        // threads
-constexpr int M_DSTR = 104;                     // halfs per pixel of a staged dcorr row (96 used; 208 B keeps 16-B pieces aligned)
+constexpr int M_DSTR = 96;                      // halfs per pixel of a staged dcorr row (12 pieces of 16 B)
 constexpr int M_OSTR = 84;                      // floats per pixel of the forward's output staging rows
 
 typedef unsigned m_u32x4 __attribute__((ext_vector_type(4)));
@@ -36,11 +37,13 @@ __device__ __forceinline__ m_u32x4 cvt_f8_bf16(float4 a, float4 b) {
     return (m_u32x4){pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
 }
 
-// Stage the halo of fp32 `src` image `n` (C channels from src, origin (ty0-4, tx0-4)) as bf16 [384][C+16].
-template <int C>
+// Stage the halo of fp32 `src` image `n` (C channels from src, origin (ty0-4, tx0-4)) as bf16 [384][YS].
+// YS = C + 16 makes the forward's b128 row reads conflict-free; C + 8 costs a 2-way conflict on half of them but lets two
+// workgroups share a CU (these kernels stage, synchronise and compute one tile per workgroup, so occupancy is what
+// overlaps their phases).
+template <int C, int YS>
 __device__ __forceinline__ void m_stage_halo(const float* __restrict__ src, int ld, int n, int H, int W, int ty0, int tx0,
                                              __bf16* ys) {
-    constexpr int YS = C + 16;
     constexpr int PPP = C / 8;                   // 16-byte bf16 pieces per pixel
     constexpr int ITEMS = MHP * PPP;
     constexpr int PER = ITEMS / M_T;             // exact: 384 * {4, 8} / 512
@@ -73,10 +76,11 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
                                                             const float* __restrict__ x2, int x2_ld, int x2_images, int H,
                                                             int W, int tilesX, int tilesY, float* __restrict__ out,
                                                             int out_ld) {
-    constexpr int YS = C + 16;
+    constexpr int YS = OUT_BF16 ? C + 8 : C + 16;
     constexpr int KS = C / 32;                   // MFMA k-steps
+    typedef typename std::conditional<OUT_BF16, __bf16, float>::type stage_t;   // staged in the output's type
     __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
-    __shared__ __attribute__((aligned(16))) float stage[MT_H * MT_W * M_OSTR];
+    __shared__ __attribute__((aligned(16))) stage_t stage[MT_H * MT_W * M_OSTR];
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
@@ -97,9 +101,9 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
             xb[s] = __builtin_bit_cast(bf16x8, cvt_f8_bf16(a, b));
         }
     }
-    m_stage_halo<C>(x2, x2_ld, n % x2_images, H, W, ty * MT_H, tx * MT_W, ys);
-    float* srow = stage + (r * MT_W) * M_OSTR;
-    if (lane < 16) { srow[lane * M_OSTR + 81] = 0.f; srow[lane * M_OSTR + 82] = 0.f; srow[lane * M_OSTR + 83] = 0.f; }
+    m_stage_halo<C, YS>(x2, x2_ld, n % x2_images, H, W, ty * MT_H, tx * MT_W, ys);
+    stage_t* srow = stage + (r * MT_W) * M_OSTR;
+    if (lane < 16) { srow[lane * M_OSTR + 81] = (stage_t)0.f; srow[lane * M_OSTR + 82] = (stage_t)0.f; srow[lane * M_OSTR + 83] = (stage_t)0.f; }
     __syncthreads();
 
     const float inv = 1.f / (float)C;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
             for (int e = 0; e < 4; ++e) {
                 const int m = 4 * g + e;
                 const int j = qb * 8 + m - p;
-                if (j >= 0 && j <= 8 && (qb == 0 || m >= 8)) srow[p * M_OSTR + i * MN + j] = acc[e] * inv;
+                if (j >= 0 && j <= 8 && (qb == 0 || m >= 8)) srow[p * M_OSTR + i * MN + j] = (stage_t)(acc[e] * inv);
             }
         }
     }
@@ -133,14 +137,13 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
         for (int item = lane; item < MT_W * ppp; item += 64) {
             const int px = item / ppp, q = item - px * ppp;
             if (tx * MT_W + px >= W) continue;
-            m_u32x4 v = {0u, 0u, 0u, 0u};
-            if (8 * q < M_OSTR) {
-                const float4 a = ld4(srow + px * M_OSTR + 8 * q);
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (8 * q + 4 < M_OSTR) b = ld4(srow + px * M_OSTR + 8 * q + 4);
-                v = cvt_f8_bf16(a, b);
-            }
-            *reinterpret_cast<m_u32x4*>(o16 + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 8 * q) = v;
+            // staged row: 84 bf16 = 168 B per pixel, so pieces are read as 8-byte halves (8-B aligned)
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            u2 lo = {0u, 0u}, hi = {0u, 0u};
+            if (8 * q < M_OSTR) lo = *reinterpret_cast<const u2*>(srow + px * M_OSTR + 8 * q);
+            if (8 * q + 4 < M_OSTR) hi = *reinterpret_cast<const u2*>(srow + px * M_OSTR + 8 * q + 4);
+            *reinterpret_cast<m_u32x4*>(o16 + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 8 * q) =
+                (m_u32x4){lo[0], lo[1], hi[0], hi[1]};
         }
     } else {
         const int ppp = out_ld / 4;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
                                                             int other_images, int H, int W, int tilesX, int tilesY,
                                                             float* __restrict__ dx, int dx_ld, int dx_coff,
                                                             int accumulate) {
-    constexpr int YS = C + 16;
+    constexpr int YS = WHICH == 1 ? C + 8 : C + 16;
     constexpr int NCB = C / 16;
     constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
     __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
             *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = v;
         }
     }
-    m_stage_halo<C>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys);
+    m_stage_halo<C, YS>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys);
     __syncthreads();
 
     f32x4 acc[NCB];

@@ -118,6 +118,7 @@ template <int CIN, int ACT_BF16>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ frames, int B, int T,
                                                          int H, int W, SlotMap sm,
                                                          const float* __restrict__ dout, int dout_ld,
+                                                         const float* __restrict__ dout2, int dout2_ld,
                                                          const float* __restrict__ act, int act_ld,
                                                          int F, long nseg, int segsX, float* __restrict__ part) {
     __shared__ float4 buf[256];
@@ -140,12 +141,20 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
         win.load_col(0, x0 - 1);
         win.load_col(1, x0);
         const size_t prow0 = (size_t)(n * H + y) * W;
-        float4 g = ld4(dout + (prow0 + x0) * dout_ld + 4 * c4);
+        auto ldg = [&](size_t pp) -> float4 {                 // gradient of the head features: dout (+ dout2, the skip path)
+            float4 v = ld4(dout + pp * dout_ld + 4 * c4);
+            if (dout2) {
+                const float4 u = ld4(dout2 + pp * dout2_ld + 4 * c4);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            return v;
+        };
+        float4 g = ldg(prow0 + x0);
         float4 a = ldx4(act, (prow0 + x0) * act_ld + 4 * c4, ACT_BF16);
         for (int x = x0; x < x1; ++x) {
             win.load_col(2, x + 1);
             const int xn = x + 1 < x1 ? x + 1 : x;              // next pixel's gradient / activation, one ahead
-            const float4 gn = ld4(dout + (prow0 + xn) * dout_ld + 4 * c4);
+            const float4 gn = ldg(prow0 + xn);
             const float4 an = ldx4(act, (prow0 + xn) * act_ld + 4 * c4, ACT_BF16);
             if (!(a.x > 0.f)) g.x = 0.f;
             if (!(a.y > 0.f)) g.y = 0.f;
@@ -844,12 +853,12 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
 }
 
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, const int* t_of_slot_host,
-                   int nslots, const float* dout, int dout_ld, const float* act, int act_ld, int F,
-                   float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
+                   int nslots, const float* dout, int dout_ld, const float* dout2, int dout2_ld, const float* act,
+                   int act_ld, int F, float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
                    int accumulate, int act_bf16, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_wgrad: in_channels %d not supported (1 or 3)", Cin);
     NVQ_REQUIRE(pow2_c4(F), "head_wgrad: F %d must be a power of two in [4,256]", F);
-    NVQ_REQUIRE(dout_ld % 4 == 0 && act_ld % 4 == 0, "head_wgrad: ld");
+    NVQ_REQUIRE(dout_ld % 4 == 0 && act_ld % 4 == 0 && (!dout2 || dout2_ld % 4 == 0), "head_wgrad: ld");
     SlotMap sm;
     for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
     const int K = Cin * 9;
@@ -861,7 +870,7 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     if (row * nblk * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
 #define NVQ_LAUNCH_HW(CIN, AB) \
-    hipLaunchKernelGGL((head_wgrad_kernel<CIN, AB>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, act, act_ld, F, nseg, segsX, workspace)
+    hipLaunchKernelGGL((head_wgrad_kernel<CIN, AB>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, dout, dout_ld, dout2, dout2_ld, act, act_ld, F, nseg, segsX, workspace)
     if (Cin == 3) { if (act_bf16) NVQ_LAUNCH_HW(3, 1); else NVQ_LAUNCH_HW(3, 0); }
     else { if (act_bf16) NVQ_LAUNCH_HW(1, 1); else NVQ_LAUNCH_HW(1, 0); }
 #undef NVQ_LAUNCH_HW

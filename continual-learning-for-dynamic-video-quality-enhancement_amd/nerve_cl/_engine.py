@@ -345,9 +345,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         dx = _new(dev, NI, H, W, F, dtype=act_dtype if k > 0 else torch.float32)
         K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
         dcur = dx
-    K.axpy_slice(Sl(dcur), Sl(dfeat_all))     # + the skip  feat = body(h) + h
+    # the skip path of  feat = body(h) + h  is summed inside the head kernel (dout2)
     K.head_wgrad(sv.frames, g.slots, dcur, sv.feat0, G["feature_extractor.head.0.weight"],
-                 G["feature_extractor.head.0.bias"], ws)
+                 G["feature_extractor.head.0.bias"], ws, dout2=dfeat_all)
 
 
 # ----------------------------------------------------------------------------- LightweightSuperResolution

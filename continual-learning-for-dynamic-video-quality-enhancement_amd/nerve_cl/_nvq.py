@@ -73,7 +73,7 @@ SIGNATURES = {
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
     "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp]),
-    "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
+    "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
     "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp]),
     "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, ci, vp]),
@@ -341,11 +341,13 @@ def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: 
                                  ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), stream()), "nvq_head_forward")
 
 
-def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, dbias, ws, accumulate=False):
+def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, dbias, ws, accumulate=False,
+               dout2: Optional[torch.Tensor] = None):
     B, T, Cin, H, W = frames.shape
     F = dweight.shape[0]
     check(lib().nvq_head_wgrad(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(dout),
-                               dout.shape[-1], ptr(act), act.shape[-1], F, ptr(dweight), ptr(dbias), ptr(ws),
+                               dout.shape[-1], ptr(dout2), dout2.shape[-1] if dout2 is not None else 0, ptr(act),
+                               act.shape[-1], F, ptr(dweight), ptr(dbias), ptr(ws),
                                ws.numel() * 4, int(accumulate), is_bf16(act), stream()), "nvq_head_wgrad")
 
 

@@ -128,10 +128,12 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots,
                      const float* weight, const float* bias, int F,
                      float* out, int out_ld, int out_bf16, void* stream);
-/* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from dout masked by (act > 0). */
+/* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from (dout + dout2) masked by (act > 0); dout2 may be NULL
+ * (it is the skip path of `features = body(h) + h`, summed here instead of in a separate pass). */
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
                    const int* t_of_slot_host, int nslots,
-                   const float* dout, int dout_ld, const float* act, int act_ld, int F,
+                   const float* dout, int dout_ld, const float* dout2, int dout2_ld,
+                   const float* act, int act_ld, int F,
                    float* dweight, float* dbias, float* workspace, size_t workspace_bytes,
                    int accumulate, int act_bf16, void* stream);
 

@@ -195,6 +195,11 @@ def test_head_forward_and_wgrad(K, Fc, B, T, H, W):
     dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
     K.head_wgrad(frames.cuda(), slots, to_nhwc(dout.reshape(T * B, Fc, H, W)), out16, dw2, db2, ws_tensor(K))
     assert rel(dw2, w.grad) < TOL and rel(db2, b.grad) < TOL
+    # gradient given as the sum of two tensors (skip path fused into the kernel)
+    d1 = to_nhwc((0.25 * dout).reshape(T * B, Fc, H, W))
+    d2 = to_nhwc((0.75 * dout).reshape(T * B, Fc, H, W), Fc + 4)
+    K.head_wgrad(frames.cuda(), slots, d1, out16, dw2, db2, ws_tensor(K), dout2=d2)
+    assert rel(dw2, w.grad) < TOL and rel(db2, b.grad) < TOL
 
 
 @pytest.mark.parametrize("C,N,H,W", [(32, 2, 9, 14), (64, 1, 7, 33), (16, 3, 5, 5)])
