@@ -53,8 +53,12 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
         const int row = 2 * wave + (pb >> 1);
         const int gy = ty * th + row;
         const int gx = tx * TW + (pb & 1) * 16 + c;
-        if (gy >= H || gx >= W) continue;
+        if (gy >= H || gx >= W) continue;        // (the 4 lanes g = 0..3 of a pixel leave together)
         const size_t pix = (size_t)(n * H + gy) * W + gx;
+        unsigned bits_in = 0, bits_out = 0;
+        if constexpr (NB <= 2) {
+            if (d.bits_mode == 2) bits_in = d.bits[pix];
+        }
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             const int co = cz * NT + cb * 16 + 4 * g;
@@ -89,6 +93,16 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                     if (!(m.z > 0.f)) v[2] = 0.f;
                     if (!(m.w > 0.f)) v[3] = 0.f;
                 }
+                if constexpr (NB <= 2) {
+                    if (d.bits_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((bits_in >> (co + e)) & 1u)) v[e] = 0.f;
+                    } else if (d.bits_mode == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << (co + e);
+                    }
+                }
                 stx4(d.out, oi, d.out_bf16, make_float4(v[0], v[1], v[2], v[3]));
             } else {
 #pragma unroll
@@ -108,6 +122,13 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                         x = 0.f;
                     *op = x;
                 }
+            }
+        }
+        if constexpr (NB <= 2) {
+            if (d.bits_mode == 1) {                // OR over the 4 lanes (g) of this pixel, lane g = 0 stores the word
+                bits_out |= __shfl_xor(bits_out, 16, 64);
+                bits_out |= __shfl_xor(bits_out, 32, 64);
+                if (g == 0) d.bits[pix] = bits_out;
             }
         }
     }

@@ -175,13 +175,17 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sv.cats, sv.resout = cats, resout
 
     # ---- residual dense blocks
+    # bf16 mode: the dense layers also emit their ReLU masks as one bit per channel (4 B per pixel) for the backward
+    use_bits = training and act_dtype == torch.bfloat16
+    sv.bits = [[_new(dev, B, H, W, dtype=torch.int32) for _ in range(LAYERS)] for _ in range(nblocks)] if use_bits else None
     for k in range(nblocks):
         cat = cats[k]
         for i in range(LAYERS):
             cin = F + GROWTH * i
             wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
             K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
-                           Sl(cat, GROWTH, cin), 3, relu=True, math=math)
+                           Sl(cat, GROWTH, cin), 3, relu=True, math=math,
+                           bits=sv.bits[k][i] if use_bits else None, bits_mode=1 if use_bits else 0)
         wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
         K.conv_forward(Sl(cat, g.CAT, 0), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
                        res=Sl(cat, F, 0), math=math)
@@ -246,8 +250,12 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
             dy = Sl(dcat, GROWTH, cinb)                      # slot of dy_i
-            K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
-                           mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math)
+            if sv.bits is not None:
+                K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
+                               math=math, bits=sv.bits[k][i], bits_mode=2)
+            else:
+                K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
+                               mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math)
             cin = F + GROWTH * i
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)

@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("accumulate", ci),
         ("math", ci),
         ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
+        ("bits", vp), ("bits_mode", ci),
     ]
 
 
@@ -263,7 +264,9 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
                  relu: bool = False, alpha: float = 1.0, accumulate: bool = False,
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
-                 mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None) -> None:
+                 mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> None:
+    """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask."""
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
     assert out.t.shape[:3] == x.t.shape[:3]
@@ -285,17 +288,21 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
     d.out2_bf16 = out2.bf16 if out2 is not None else 0
     d.res_bf16 = res.bf16 if res is not None else 0
     d.mask_bf16 = mask.bf16 if mask is not None else 0
+    if bits_mode:
+        assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape) == (n, h, w) and bits.is_contiguous()
+        d.bits, d.bits_mode = ptr(bits), bits_mode
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
     if ev0 is not None:
         cin = x.c if alg_cin is None else alg_cin
         esz = lambda sl: 2.0 if sl.bf16 else 4.0   # noqa: E731  bytes per element
         nbytes = cin * esz(x) + out.c * esz(out) * (2 if accumulate else 1) \
             + (res.c * esz(res) if res is not None else 0) + (out2.c * esz(out2) if out2 is not None else 0) \
-            + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0)
+            + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0) + (4 if bits_mode else 0)
         TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
                    n * h * w * nbytes, f"n{n} cin{x.c}{'h' if x.bf16 else ''} cout{out.c}{'h' if out.bf16 else ''}"
                    + (" acc" if accumulate else "")
-                   + (" res" if res is not None else "") + (" mask" if mask is not None else ""))
+                   + (" res" if res is not None else "") + (" mask" if mask is not None else "")
+                   + (" bitsW" if bits_mode == 1 else " bitsR" if bits_mode == 2 else ""))
 
 
 def rdb_backward_weights(lff: torch.Tensor, ws: Sequence[torch.Tensor], F: int):

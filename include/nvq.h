@@ -83,6 +83,12 @@ typedef struct nvq_conv_desc {
      * pointer, although typed float*, addresses bf16 data).  bf16 tensors need NVQ_MATH_BF16, a bf16 input
      * needs cin, in_ld, in_coff % 8 == 0, and every slice must be 8-byte addressable. */
     int in_bf16, out_bf16, out2_bf16, res_bf16, mask_bf16;
+    /* One-bit ReLU masks (NVQ_MATH_BF16, cout <= 32, vector epilogue): bits[(n*h + y)*w + x] holds bit c = "output
+     * channel c of this pixel is > 0".  bits_mode 1: written from the value stored to `out` (the dense layer's forward);
+     * bits_mode 2: read as the mask of channels [0, cout_store) instead of a `mask` tensor (its mirror-form gradient
+     * conv: 4 bytes per pixel instead of 64); 0: unused. */
+    unsigned* bits;
+    int bits_mode;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */

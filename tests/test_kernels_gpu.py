@@ -689,3 +689,28 @@ def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
                    mask=K.Sl(mb, 32, 32), mask_c0=0, mask_c1=32, math=K.MATH_BF16)
     refm = F.conv2d(cat[:, :cin], bf(w3), None, padding=1) * (m > 0)
     assert rel(from_nhwc(out), refm) < TOL
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 35, 41), (1, 9, 33)])
+def test_conv_bf16_one_bit_relu_masks(K, N, H, W):
+    """bits_mode 1 writes bit c = (stored output channel c > 0) per pixel; bits_mode 2 uses the word as the ReLU mask of the
+    mirror-form gradient conv: same result as masking with the activation tensor itself (both tile heights)."""
+    cin, ld = 96, 256
+    cat = bf(rnd(N, ld, H, W))
+    w3, b3 = rnd(32, cin, 3, 3, scale=0.1), rnd(32)
+    wp = K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16)
+    catb = to_nhwc_bf16(cat)
+    bits = torch.zeros(N, H, W, dtype=torch.int32, device="cuda")
+    K.conv_forward(K.Sl(catb, cin, 0), wp, b3.cuda(), K.Sl(catb, 32, cin), 3, relu=True, math=K.MATH_BF16, bits=bits,
+                   bits_mode=1)
+    act = catb[..., cin:cin + 32].float()
+    want = ((act > 0).to(torch.int64) << torch.arange(32, device="cuda")).sum(-1)
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, want)
+    dyb = to_nhwc_bf16(bf(rnd(N, cin, H, W, seed=4)), ld)
+    wb = K.conv_pack(rnd(32, cin, 3, 3, scale=0.1, seed=5).cuda(), False, cin, math=K.MATH_BF16)
+    out_mask = torch.empty(N, H, W, 32, device="cuda")
+    out_bits = torch.empty(N, H, W, 32, device="cuda")
+    K.conv_forward(K.Sl(dyb, cin, 0), wb, None, K.Sl(out_mask), 3, mask=K.Sl(catb, 32, cin), mask_c0=0, mask_c1=32,
+                   math=K.MATH_BF16)
+    K.conv_forward(K.Sl(dyb, cin, 0), wb, None, K.Sl(out_bits), 3, math=K.MATH_BF16, bits=bits, bits_mode=2)
+    assert torch.equal(out_mask, out_bits)
