@@ -430,10 +430,17 @@ __device__ __forceinline__ float4 dw_unpack4(dw_u32x2 v) {
                        __uint_as_float(v[1] & 0xffff0000u));
 }
 
+// Optional on-the-fly input transform of the 64-channel depthwise kernels: x := relu(bn(x)) with the statistics of the
+// image's group - the BatchNorm + ReLU between a pointwise conv and the next depthwise conv, applied while the halo is
+// staged instead of in a pass of its own (same expression and the same single bf16 rounding as bn_apply_relu_kernel, so the
+// staged values are the ones that kernel would have stored).  Zero padding stays zero.
+struct DwBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int group_images; int C; };
+
 __device__ __forceinline__ void dw_stage_halo_bf16(const __bf16* __restrict__ in, int in_ld, int n, int H, int W, int ty0,
-                                                   int tx0, int ch0, __bf16* xs) {
+                                                   int tx0, int ch0, __bf16* xs, const DwBn bn) {
     constexpr int PER = (DT_NPIX * 8 + DB_T - 1) / DB_T;
     dw_u32x4 v[PER];
+    bool okv[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {                      // all loads first (clamped addresses), then the stores
         const int item = threadIdx.x + k * DB_T;
@@ -441,9 +448,35 @@ __device__ __forceinline__ void dw_stage_halo_bf16(const __bf16* __restrict__ in
         const int hy = hp / DT_HW, hx = hp - hy * DT_HW;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool ok = item < DT_NPIX * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        okv[k] = ok;
         const size_t idx = ok ? ((size_t)(n * H + gy) * W + gx) * in_ld + ch0 + 8 * q : 0;
         v[k] = *reinterpret_cast<const dw_u32x4*>(in + idx);
         if (!ok) v[k] = (dw_u32x4){0u, 0u, 0u, 0u};
+    }
+    if (bn.mean) {                                        // uniform
+        const int c0 = ch0 + 8 * (threadIdx.x & 7);      // this thread's channel group (DB_T % 8 == 0)
+        const int g = n / bn.group_images;
+        float m[8], is[8], ga[8], be[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            m[e] = bn.mean[g * bn.C + c0 + e]; is[e] = bn.invstd[g * bn.C + c0 + e];
+            ga[e] = bn.gamma[c0 + e]; be[e] = bn.beta[c0 + e];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (!okv[k]) continue;
+            dw_u32x4 o;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const float a = __uint_as_float(v[k][w2] << 16), b = __uint_as_float(v[k][w2] & 0xffff0000u);
+                const float ya = fmaxf((a - m[2 * w2]) * is[2 * w2] * ga[2 * w2] + be[2 * w2], 0.f);
+                const float yb = fmaxf((b - m[2 * w2 + 1]) * is[2 * w2 + 1] * ga[2 * w2 + 1] + be[2 * w2 + 1], 0.f);
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                const b2 pk = {(__bf16)ya, (__bf16)yb};
+                o[w2] = __builtin_bit_cast(unsigned, pk);
+            }
+            v[k] = o;
+        }
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -460,7 +493,7 @@ __device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
 __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
-                                                           int tilesY, int flip, int out_bf16) {
+                                                           int tilesY, int flip, int out_bf16, DwBn bn) {
     __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restr
         const int c = ch0 + 4 * c4;
         w[t] = make_float4(weight[(c + 0) * 9 + tt], weight[(c + 1) * 9 + tt], weight[(c + 2) * 9 + tt], weight[(c + 3) * 9 + tt]);
     }
-    dw_stage_halo_bf16(in, in_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+    dw_stage_halo_bf16(in, in_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs, bn);
     __syncthreads();
     const int gx = tx * DT_W + x;
     float4 r[3][3];
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restr
 __global__ __launch_bounds__(DB_T) void dwconv_wgrad_bf16_kernel(const __bf16* __restrict__ x, int x_ld,
                                                                  const __bf16* __restrict__ dy, int dy_ld, int C, int H,
                                                                  int W, int tilesX, int tilesY, int ntiles,
-                                                                 float* __restrict__ part) {
+                                                                 float* __restrict__ part, DwBn bn) {
     __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
     const int ch0 = blockIdx.y * DB_C;
     const int c4 = threadIdx.x & 15, xx = threadIdx.x >> 4;
@@ -528,7 +561,7 @@ __global__ __launch_bounds__(DB_T) void dwconv_wgrad_bf16_kernel(const __bf16* _
             if (!ok) g[y] = (dw_u32x2){0u, 0u};
         }
         __syncthreads();
-        dw_stage_halo_bf16(x, x_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs);
+        dw_stage_halo_bf16(x, x_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs, bn);
         __syncthreads();
         float4 r[3][3];
 #pragma unroll
@@ -888,8 +921,16 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     return nvq_axpy_slice(dbias, F, 0, scratch + F * K, F, 0, nullptr, 0, 0, F, 1, 1.f, accumulate, stream);
 }
 
+static DwBn make_dwbn(const nvq_bn_input* b, int C) {
+    DwBn r = {nullptr, nullptr, nullptr, nullptr, 1, C};
+    if (b) { r.mean = b->mean; r.invstd = b->invstd; r.gamma = b->gamma; r.beta = b->beta; r.group_images = b->group_images; }
+    return r;
+}
+
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, float* out, int out_ld,
-                       int N, int H, int W, int flip, int in_bf16, int out_bf16, void* stream) {
+                       int N, int H, int W, int flip, int in_bf16, int out_bf16, const nvq_bn_input* bn, void* stream) {
+    NVQ_REQUIRE(!bn || (C % DB_C == 0 && in_bf16 && bn->group_images > 0 && N % bn->group_images == 0),
+                "dwconv_forward: the fused BatchNorm input needs a bf16 tensor with C %% 64 == 0");
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
                 "dwconv_forward: C %d ld %d/%d", C, in_ld, out_ld);
     if (C % DB_C == 0 && in_bf16) {
@@ -897,7 +938,7 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
         const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
         hipLaunchKernelGGL(dwconv_bf16_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DB_C), dim3(DB_T), 0,
                            (hipStream_t)stream, reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W,
-                           tilesX, tilesY, flip, out_bf16);
+                           tilesX, tilesY, flip, out_bf16, make_dwbn(bn, C));
         return check_launch("dwconv_bf16");
     }
     if (C % DT_C == 0) {
@@ -915,7 +956,10 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
 
 int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C, int N, int H, int W,
                      float* dweight, float* workspace, size_t workspace_bytes, int accumulate,
-                     int x_bf16, int dy_bf16, void* stream) {
+                     int x_bf16, int dy_bf16, const nvq_bn_input* bn, void* stream) {
+    NVQ_REQUIRE(!bn || (C % DB_C == 0 && x_bf16 && dy_bf16 && x_ld % 8 == 0 && dy_ld % 8 == 0 && bn->group_images > 0 &&
+                        N % bn->group_images == 0),
+                "dwconv_wgrad: the fused BatchNorm input needs bf16 tensors with C %% 64 == 0");
     NVQ_REQUIRE(pow2_c4(C), "dwconv_wgrad: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(x_ld % 4 == 0 && dy_ld % 4 == 0, "dwconv_wgrad: ld");
     const long npix = (long)N * H * W;
@@ -926,7 +970,7 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
         if ((size_t)nb * C * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_wgrad: workspace"); return NVQ_EWORKSPACE; }
         hipLaunchKernelGGL(dwconv_wgrad_bf16_kernel, dim3(nb, C / DB_C), dim3(DB_T), 0, (hipStream_t)stream,
                            reinterpret_cast<const __bf16*>(x), x_ld, reinterpret_cast<const __bf16*>(dy), dy_ld, C, H, W,
-                           tilesX, tilesY, ntiles, workspace);
+                           tilesX, tilesY, ntiles, workspace, make_dwbn(bn, C));
         int rc0 = check_launch("dwconv_wgrad_bf16");
         if (rc0) return rc0;
         return launch_reduce_partials(workspace, nb, C * 9, 1.f, dweight, accumulate, (hipStream_t)stream);

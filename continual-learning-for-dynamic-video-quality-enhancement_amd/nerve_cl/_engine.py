@@ -93,11 +93,14 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     feat_oth = _new(dev, max(NO, 1), H, W, F)
     sv.feat0, sv.aligned, sv.feat_oth = feat0, aligned, feat_oth
     sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = [], [], [], [], []
-    cur = feat0
+    cur, cur_bn = feat0, None         # cur_bn: BatchNorm + ReLU still to be applied to `cur` (fused into the consumer)
+    sv.dw_in = []                     # (tensor, bn) the depthwise conv of layer k was fed with
+    fuse_bn = K.dwconv_bn_fusable(feat0, F)
     for k in range(3):
         pre = f"feature_extractor.body.{k}."
         d = _new(dev, NI, H, W, F, dtype=act_dtype)
-        K.dwconv_forward(cur, P[pre + "depthwise.weight"], d)
+        K.dwconv_forward(cur, P[pre + "depthwise.weight"], d, bn=cur_bn)
+        sv.dw_in.append((cur, cur_bn))
         p = _new(dev, NI, H, W, F, dtype=act_dtype)
         wp = K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math)
         K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
@@ -108,8 +111,11 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             P[pre + "bn.num_batches_tracked"].add_(T)
         else:
             K.bn_eval_stats(P[pre + "bn.running_mean"], P[pre + "bn.running_var"], T, mean, invstd, BN_EPS)
-        if k < 2:
-            r = _new(dev, NI, H, W, F, dtype=act_dtype)
+        if k < 2 and fuse_bn:
+            # relu(bn(p)) is evaluated by the next depthwise conv (and by its weight gradient) while it stages p
+            r, cur_bn = p, (mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], B)
+        elif k < 2:
+            r, cur_bn = _new(dev, NI, H, W, F, dtype=act_dtype), None
             K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], None, Sl(r), NI)
         else:
             # features = relu(bn(.)) + head features; centre frame lands in its slot of `aligned`
@@ -348,8 +354,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
         dd = _new(dev, NI, H, W, F, dtype=act_dtype)
         K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
-        xin = sv.feat0 if k == 0 else sv.acts[k - 1]
-        K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws)
+        xin, xin_bn = sv.dw_in[k]
+        K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws, bn=xin_bn)
         dx = _new(dev, NI, H, W, F, dtype=act_dtype if k > 0 else torch.float32)
         K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
         dcur = dx

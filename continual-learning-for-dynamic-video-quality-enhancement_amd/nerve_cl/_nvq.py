@@ -45,6 +45,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BnInput(C.Structure):
+    _fields_ = [("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp), ("group_images", ci)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", vp), ("x_ld", ci), ("x_coff", ci), ("cin", ci), ("cin_w", ci),
@@ -75,8 +79,8 @@ SIGNATURES = {
     "nvq_sizeof_wgrad_desc": (sz, []),
     "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
-    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
-    "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp]),
+    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp, vp]),
     "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, ci, vp]),
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
@@ -358,18 +362,36 @@ def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, db
                                ws.numel() * 4, int(accumulate), is_bf16(act), stream()), "nvq_head_wgrad")
 
 
-def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False):
+def _bn_input(bn) -> "Optional[BnInput]":
+    """bn = (mean, invstd, gamma, beta, group_images) or None."""
+    if bn is None:
+        return None
+    b = BnInput()
+    b.mean, b.invstd, b.gamma, b.beta, b.group_images = ptr(bn[0]), ptr(bn[1]), ptr(bn[2]), ptr(bn[3]), int(bn[4])
+    return b
+
+
+def dwconv_bn_fusable(x: torch.Tensor, C: int) -> bool:
+    """True when the depthwise kernels can evaluate relu(bn(x)) while staging x (bf16 tensor, C % 64 == 0)."""
+    return x.dtype == torch.bfloat16 and C % 64 == 0
+
+
+def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False, bn=None):
     N, H, W, ld = x.shape
     Cc = weight.shape[0]
+    b = _bn_input(bn)
     check(lib().nvq_dwconv_forward(ptr(x), ld, ptr(weight), Cc, ptr(out), out.shape[-1], N, H, W, int(flip),
-                                   is_bf16(x), is_bf16(out), stream()), "nvq_dwconv_forward")
+                                   is_bf16(x), is_bf16(out), C.byref(b) if b is not None else None, stream()),
+          "nvq_dwconv_forward")
 
 
-def dwconv_wgrad(x: torch.Tensor, dy: torch.Tensor, dweight, ws, accumulate=False):
+def dwconv_wgrad(x: torch.Tensor, dy: torch.Tensor, dweight, ws, accumulate=False, bn=None):
     N, H, W, ld = x.shape
     Cc = dweight.shape[0]
+    b = _bn_input(bn)
     check(lib().nvq_dwconv_wgrad(ptr(x), ld, ptr(dy), dy.shape[-1], Cc, N, H, W, ptr(dweight), ptr(ws),
-                                 ws.numel() * 4, int(accumulate), is_bf16(x), is_bf16(dy), stream()), "nvq_dwconv_wgrad")
+                                 ws.numel() * 4, int(accumulate), is_bf16(x), is_bf16(dy),
+                                 C.byref(b) if b is not None else None, stream()), "nvq_dwconv_wgrad")
 
 
 def bn_stats(x: torch.Tensor, group_images: int, order: Sequence[int], mean, invstd, rmean, rvar, ws,

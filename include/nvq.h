@@ -146,12 +146,20 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
 /* Depthwise 3x3 (groups = C, no bias), efficient_layers.py:38-46.  weight [C][1][3][3].
  * flip == 1 gives the input gradient.  The *_bf16 flags of this section give the storage type of the
  * corresponding activation tensor (0 = fp32, 1 = bf16; arithmetic and statistics stay fp32). */
+/* bn != NULL (bf16 input, C % 64 == 0): the kernel's input is relu(batchnorm(in)) evaluated on the fly with the given
+ * per-(group, channel) statistics - the BatchNorm + ReLU of DepthwiseSeparableConv k feeding the depthwise conv of k+1
+ * (efficient_layers.py:62-67) without a pass of its own.  mean/invstd: [N/group_images][C]; gamma/beta: [C]. */
+typedef struct nvq_bn_input {
+    const float* mean; const float* invstd; const float* gamma; const float* beta;
+    int group_images;
+} nvq_bn_input;
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C,
                        float* out, int out_ld, int N, int H, int W, int flip,
-                       int in_bf16, int out_bf16, void* stream);
+                       int in_bf16, int out_bf16, const nvq_bn_input* bn, void* stream);
 int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C,
                      int N, int H, int W, float* dweight, float* workspace,
-                     size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16, void* stream);
+                     size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16,
+                     const nvq_bn_input* bn, void* stream);
 
 /* BatchNorm2d, efficient_layers.py:59,65.  The N images form G = N/group_images groups
  * (one per feature-extractor call); statistics are per (group, channel) over

@@ -714,3 +714,26 @@ def test_conv_bf16_one_bit_relu_masks(K, N, H, W):
                    math=K.MATH_BF16)
     K.conv_forward(K.Sl(dyb, cin, 0), wb, None, K.Sl(out_bits), 3, math=K.MATH_BF16, bits=bits, bits_mode=2)
     assert torch.equal(out_mask, out_bits)
+
+
+def test_dwconv_bf16_with_fused_batchnorm_input(K):
+    """bn=(mean, invstd, gamma, beta, group_images): the depthwise kernels consume relu(bn(x)) evaluated while staging x;
+    must equal bn_apply_relu (bf16 output) followed by the plain kernels, bit for bit."""
+    C, B, G, H, W = 64, 2, 3, 19, 37
+    N = B * G
+    p = to_nhwc_bf16(bf(rnd(N, C, H, W) * 1.5 + 0.2))
+    w = rnd(C, 1, 3, 3).cuda()
+    mean, invstd = (0.3 * rnd(G, C)).cuda(), (1.0 + 0.5 * rnd(G, C, seed=2).abs()).cuda()
+    gamma, beta = (1 + 0.2 * rnd(C, seed=3)).cuda(), (0.1 * rnd(C, seed=4)).cuda()
+    r = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.bn_apply_relu(p, B, mean, invstd, gamma, beta, None, K.Sl(r), N)
+    bn = (mean, invstd, gamma, beta, B)
+    a, b = torch.empty_like(r), torch.empty_like(r)
+    K.dwconv_forward(r, w, a)
+    K.dwconv_forward(p, w, b, bn=bn)
+    assert torch.equal(a, b)
+    dy = to_nhwc_bf16(bf(rnd(N, C, H, W, seed=6)))
+    dwa, dwb = torch.empty(C, 1, 3, 3, device="cuda"), torch.empty(C, 1, 3, 3, device="cuda")
+    K.dwconv_wgrad(r, dy, dwa, ws_tensor(K))
+    K.dwconv_wgrad(p, dy, dwb, ws_tensor(K), bn=bn)
+    assert torch.equal(dwa, dwb)
