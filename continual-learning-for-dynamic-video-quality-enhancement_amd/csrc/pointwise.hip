@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ weight,
                                                        const float* __restrict__ bias, int F,
                                                        float* __restrict__ out, int out_ld, int out_bf16,
-                                                       long nseg, int segsX) {
+                                                       __bf16* __restrict__ img8, long nseg, int segsX) {
     constexpr int K = CIN * 9;
     const int F4 = F >> 2;
     const int npl = 256 / F4;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                     }
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
             stx4(out, orow + (size_t)x * out_ld, out_bf16, acc);
+            if (img8 && c4 == 0) {                            // the frame itself as bf16 NHWC-8 (slot order), see nvq.h
+                bf16x8 px = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) px[ci] = (__bf16)win.v[ci][1][1];
+                *reinterpret_cast<bf16x8*>(img8 + ((size_t)(n * H + y) * W + x) * 8) = px;
+            }
             win.shift();
         }
     }
@@ -434,6 +440,8 @@ __device__ __forceinline__ float4 dw_unpack4(dw_u32x2 v) {
 // image's group - the BatchNorm + ReLU between a pointwise conv and the next depthwise conv, applied while the halo is
 // staged instead of in a pass of its own (same expression and the same single bf16 rounding as bn_apply_relu_kernel, so the
 // staged values are the ones that kernel would have stored).  Zero padding stays zero.
+// Optional epilogue of dwconv_bf16_kernel: out = (conv + add) masked by (mask > 0); add is fp32, mask bf16 or fp32.
+struct DwEpi { const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16; };
 struct DwBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int group_images; int C; };
 
 __device__ __forceinline__ void dw_stage_halo_bf16(const __bf16* __restrict__ in, int in_ld, int n, int H, int W, int ty0,
@@ -493,7 +501,7 @@ __device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
 __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
-                                                           int tilesY, int flip, int out_bf16, DwBn bn) {
+                                                           int tilesY, int flip, int out_bf16, DwBn bn, DwEpi ep) {
     __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
@@ -529,7 +537,21 @@ __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restr
                 acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
             }
         const int gy = ty * DT_H + y;
-        if (gy < H && gx < W) stx4(out, ((size_t)(n * H + gy) * W + gx) * out_ld + ch0 + 4 * c4, out_bf16, acc);
+        if (gy < H && gx < W) {
+            const size_t pix = (size_t)(n * H + gy) * W + gx;
+            if (ep.add) {
+                const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            }
+            if (ep.mask) {
+                const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
+                if (!(m.x > 0.f)) acc.x = 0.f;
+                if (!(m.y > 0.f)) acc.y = 0.f;
+                if (!(m.z > 0.f)) acc.z = 0.f;
+                if (!(m.w > 0.f)) acc.w = 0.f;
+            }
+            stx4(out, pix * out_ld + ch0 + 4 * c4, out_bf16, acc);
+        }
 #pragma unroll
         for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
     }
@@ -866,7 +888,7 @@ extern "C" {
 
 int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots, const float* weight, const float* bias,
-                     int F, float* out, int out_ld, int out_bf16, void* stream) {
+                     int F, float* out, int out_ld, int out_bf16, float* img8, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_forward: in_channels %d not supported (1 or 3)", Cin);
     NVQ_REQUIRE(pow2_c4(F) && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d (power of two in [4,256]) / ld %d", F, out_ld);
     NVQ_REQUIRE(nslots >= 1 && nslots <= NVQ_MAX_T && T <= NVQ_MAX_T, "head_forward: T %d slots %d", T, nslots);
@@ -879,9 +901,9 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
     if (nblk > 2048) nblk = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 3)
-        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, nseg, segsX);
+        hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, reinterpret_cast<__bf16*>(img8), nseg, segsX);
     else
-        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, nseg, segsX);
+        hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, reinterpret_cast<__bf16*>(img8), nseg, segsX);
     return check_launch("head_forward");
 }
 
@@ -928,7 +950,13 @@ static DwBn make_dwbn(const nvq_bn_input* b, int C) {
 }
 
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, float* out, int out_ld,
-                       int N, int H, int W, int flip, int in_bf16, int out_bf16, const nvq_bn_input* bn, void* stream) {
+                       int N, int H, int W, int flip, int in_bf16, int out_bf16, const nvq_bn_input* bn,
+                       const nvq_dw_epilogue* epi, void* stream) {
+    NVQ_REQUIRE(!epi || (C % DB_C == 0 && in_bf16 && (!epi->add || epi->add_ld % 4 == 0) &&
+                         (!epi->mask || epi->mask_ld % 4 == 0)),
+                "dwconv_forward: the add / mask epilogue needs a bf16 input with C %% 64 == 0");
+    DwEpi ep = {nullptr, 0, nullptr, 0, 0};
+    if (epi) { ep.add = epi->add; ep.add_ld = epi->add_ld; ep.mask = epi->mask; ep.mask_ld = epi->mask_ld; ep.mask_bf16 = epi->mask_bf16; }
     NVQ_REQUIRE(!bn || (C % DB_C == 0 && in_bf16 && bn->group_images > 0 && N % bn->group_images == 0),
                 "dwconv_forward: the fused BatchNorm input needs a bf16 tensor with C %% 64 == 0");
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
@@ -938,7 +966,7 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
         const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
         hipLaunchKernelGGL(dwconv_bf16_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DB_C), dim3(DB_T), 0,
                            (hipStream_t)stream, reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W,
-                           tilesX, tilesY, flip, out_bf16, make_dwbn(bn, C));
+                           tilesX, tilesY, flip, out_bf16, make_dwbn(bn, C), ep);
         return check_launch("dwconv_bf16");
     }
     if (C % DT_C == 0) {

@@ -88,7 +88,10 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
     # ---- feature extractor, all T frames in one batch (slot order)
     feat0 = _new(dev, NI, H, W, F, dtype=act_dtype)
-    K.head_forward(frames, g.slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0)
+    # bf16 mode: the head's weight gradient runs on the matrix cores (conv_wgrad over the frames as bf16 NHWC-8)
+    sv.img8 = _new(dev, NI, H, W, 8, dtype=torch.bfloat16) if (training and K.dwconv_bn_fusable(feat0, F)) else None
+    K.head_forward(frames, g.slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0,
+                   img8=sv.img8)
     aligned = _new(dev, B, H, W, T * F)
     feat_oth = _new(dev, max(NO, 1), H, W, F)
     sv.feat0, sv.aligned, sv.feat_oth = feat0, aligned, feat_oth
@@ -356,12 +359,21 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin, xin_bn = sv.dw_in[k]
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws, bn=xin_bn)
-        dx = _new(dev, NI, H, W, F, dtype=act_dtype if k > 0 else torch.float32)
-        K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
+        if k == 0 and sv.img8 is not None:
+            # dx + skip path, ReLU-masked by the head features: the gradient of the head conv, as bf16
+            dx = _new(dev, NI, H, W, F, dtype=act_dtype)
+            K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True, add=dfeat_all, mask=sv.feat0)
+        else:
+            dx = _new(dev, NI, H, W, F, dtype=act_dtype if k > 0 else torch.float32)
+            K.dwconv_forward(dd, P[pre + "depthwise.weight"], dx, flip=True)
         dcur = dx
-    # the skip path of  feat = body(h) + h  is summed inside the head kernel (dout2)
-    K.head_wgrad(sv.frames, g.slots, dcur, sv.feat0, G["feature_extractor.head.0.weight"],
-                 G["feature_extractor.head.0.bias"], ws, dout2=dfeat_all)
+    if sv.img8 is not None:
+        K.conv_wgrad(Sl(sv.img8), g.Cimg, Sl(dcur), G["feature_extractor.head.0.weight"],
+                     G["feature_extractor.head.0.bias"], ws, 3, math=math)
+    else:
+        # the skip path of  feat = body(h) + h  is summed inside the head kernel (dout2)
+        K.head_wgrad(sv.frames, g.slots, dcur, sv.feat0, G["feature_extractor.head.0.weight"],
+                     G["feature_extractor.head.0.bias"], ws, dout2=dfeat_all)
 
 
 # ----------------------------------------------------------------------------- LightweightSuperResolution

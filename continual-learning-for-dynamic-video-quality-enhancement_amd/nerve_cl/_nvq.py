@@ -45,6 +45,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class DwEpilogue(C.Structure):
+    _fields_ = [("add", vp), ("add_ld", ci), ("mask", vp), ("mask_ld", ci), ("mask_bf16", ci)]
+
+
 class BnInput(C.Structure):
     _fields_ = [("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp), ("group_images", ci)]
 
@@ -77,9 +81,9 @@ SIGNATURES = {
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
-    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
-    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp, vp]),
     "nvq_bn_stats": (ci, [vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, ci, vp]),
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
@@ -345,11 +349,14 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
 
 
 # ----------------------------------------------------------------------------- feature extractor
-def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: torch.Tensor) -> None:
+def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: torch.Tensor,
+                 img8: Optional[torch.Tensor] = None) -> None:
     B, T, Cin, H, W = frames.shape
     F = weight.shape[0]
+    assert img8 is None or (img8.dtype == torch.bfloat16 and tuple(img8.shape) == (len(slots) * B, H, W, 8))
     check(lib().nvq_head_forward(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(weight),
-                                 ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), stream()), "nvq_head_forward")
+                                 ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), ptr(img8), stream()),
+          "nvq_head_forward")
 
 
 def head_wgrad(frames, slots, dout: torch.Tensor, act: torch.Tensor, dweight, dbias, ws, accumulate=False,
@@ -376,12 +383,20 @@ def dwconv_bn_fusable(x: torch.Tensor, C: int) -> bool:
     return x.dtype == torch.bfloat16 and C % 64 == 0
 
 
-def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False, bn=None):
+def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False, bn=None,
+                   add: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
+    """add (fp32) / mask (fp32 or bf16), both [N,H,W,>=C]: out = (conv + add) where mask > 0 (64-channel bf16 kernels)."""
     N, H, W, ld = x.shape
     Cc = weight.shape[0]
     b = _bn_input(bn)
+    e = None
+    if add is not None or mask is not None:
+        e = DwEpilogue()
+        e.add, e.add_ld = ptr(add), add.shape[-1] if add is not None else 0
+        e.mask, e.mask_ld, e.mask_bf16 = ptr(mask), mask.shape[-1] if mask is not None else 0, is_bf16(mask)
     check(lib().nvq_dwconv_forward(ptr(x), ld, ptr(weight), Cc, ptr(out), out.shape[-1], N, H, W, int(flip),
-                                   is_bf16(x), is_bf16(out), C.byref(b) if b is not None else None, stream()),
+                                   is_bf16(x), is_bf16(out), C.byref(b) if b is not None else None,
+                                   C.byref(e) if e is not None else None, stream()),
           "nvq_dwconv_forward")
 
 

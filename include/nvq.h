@@ -133,7 +133,9 @@ size_t nvq_sizeof_wgrad_desc(void);
 int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots,
                      const float* weight, const float* bias, int F,
-                     float* out, int out_ld, int out_bf16, void* stream);
+                     float* out, int out_ld, int out_bf16, float* img8, void* stream);
+/* img8 (optional, bf16 [nslots*B][H][W][8]): the frames themselves in slot order, channels 0..Cin-1 (rest zero) - the
+ * x operand with which nvq_conv_wgrad computes the head's weight gradient on the matrix cores in bf16 mode. */
 /* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from (dout + dout2) masked by (act > 0); dout2 may be NULL
  * (it is the skip path of `features = body(h) + h`, summed here instead of in a separate pass). */
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,
@@ -153,9 +155,16 @@ typedef struct nvq_bn_input {
     const float* mean; const float* invstd; const float* gamma; const float* beta;
     int group_images;
 } nvq_bn_input;
+/* epi != NULL (same kernels): out = (conv + add) where mask > 0, else 0.  add: fp32 [.., add_ld] or NULL; mask: fp32 or
+ * bf16 [.., mask_ld] or NULL.  Used for the last depthwise input gradient of the feature extractor, which so leaves the
+ * kernel as the ReLU-masked gradient of the head conv (skip path added). */
+typedef struct nvq_dw_epilogue {
+    const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16;
+} nvq_dw_epilogue;
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C,
                        float* out, int out_ld, int N, int H, int W, int flip,
-                       int in_bf16, int out_bf16, const nvq_bn_input* bn, void* stream);
+                       int in_bf16, int out_bf16, const nvq_bn_input* bn, const nvq_dw_epilogue* epi,
+                       void* stream);
 int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C,
                      int N, int H, int W, float* dweight, float* workspace,
                      size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16,

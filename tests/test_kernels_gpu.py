@@ -737,3 +737,37 @@ def test_dwconv_bf16_with_fused_batchnorm_input(K):
     K.dwconv_wgrad(r, dy, dwa, ws_tensor(K))
     K.dwconv_wgrad(p, dy, dwb, ws_tensor(K), bn=bn)
     assert torch.equal(dwa, dwb)
+
+
+def test_head_gradient_through_matrix_core_wgrad(K):
+    """bf16 mode's head weight gradient: head_forward also emits the frames as bf16 NHWC-8, the last depthwise input
+    gradient leaves its kernel as (dx + skip) masked by the head features, and nvq_conv_wgrad does the rest."""
+    Fc, B, T, H, W = 64, 2, 3, 19, 37
+    frames = bf(rnd(B, T, 3, H, W).abs())
+    w = rnd(Fc, 3, 3, 3, scale=0.4).requires_grad_()
+    b = rnd(Fc, scale=0.1).requires_grad_()
+    slots = [1, 0, 2]
+    feat = torch.stack([F.relu(F.conv2d(frames[:, t], w, b, padding=1)) for t in slots], 0)   # [slot,B,F,H,W]
+    NI = T * B
+    feat16 = torch.empty(NI, H, W, Fc, device="cuda", dtype=torch.bfloat16)
+    img8 = torch.full((NI, H, W, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    K.head_forward(frames.cuda(), slots, w.detach().cuda(), b.detach().cuda(), feat16, img8=img8)
+    want_img = torch.stack([frames[:, t] for t in slots], 0).reshape(NI, 3, H, W)
+    assert torch.equal(img8[..., :3].float().cpu(), want_img.permute(0, 2, 3, 1)) and img8[..., 3:].abs().max().item() == 0
+    # depthwise input gradient with the add / mask epilogue
+    dd = bf(rnd(NI, Fc, H, W, seed=3))
+    wd = rnd(Fc, 1, 3, 3)
+    skip = rnd(NI, Fc, H, W, seed=4)
+    xg = torch.zeros(NI, Fc, H, W, requires_grad=True)
+    F.conv2d(xg, wd, None, padding=1, groups=Fc).backward(dd)
+    mask_ref = from_nhwc(feat16.float()) > 0
+    ghead = (xg.grad + skip) * mask_ref
+    dx = torch.empty(NI, H, W, Fc, device="cuda", dtype=torch.bfloat16)
+    K.dwconv_forward(to_nhwc_bf16(dd), wd.cuda(), dx, flip=True, add=to_nhwc(skip), mask=feat16)
+    assert rel(from_nhwc(dx.float()), ghead) < 5e-3
+    # weight / bias gradient of the head conv from (img8, dx)
+    gh = from_nhwc(dx.float()).reshape(T, B, Fc, H, W)
+    feat.backward(gh * (feat.detach() > 0))          # reference: the same (bf16-rounded) gradient through conv + ReLU
+    dw, db = torch.empty(Fc, 3, 3, 3, device="cuda"), torch.empty(Fc, device="cuda")
+    K.conv_wgrad(K.Sl(img8), 3, K.Sl(dx), dw, db, ws_tensor(K), 3, math=K.MATH_BF16)
+    assert rel(dw, w.grad) < TOL and rel(db, b.grad) < TOL
