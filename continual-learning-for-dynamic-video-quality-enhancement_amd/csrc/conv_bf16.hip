@@ -255,6 +255,189 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_);
 }
 
+// ---------------------------------------------------------------- dense-block tail: last 3x3 layer + 1x1 lff, fused
+// ResidualDenseBlock.forward (super_resolution.py:245-253) ends with  y4 = relu(conv3x3(cat[0:C])),  out = 0.2 *
+// lff(cat[0:C+32]) + x.  Run separately, the 1x1 reads the whole concat buffer again (448 B per pixel for 64 + 128 B of
+// residual and output).  Here the 3x3 kernel's K loop also feeds every staged 32-channel chunk to the 1x1 (the centre-tap
+// fragments of the 3x3 ARE the 1x1's operands), and the tile's own y4 goes from the accumulators through LDS into the
+// 1x1's last K step, so lff costs 16 extra MFMAs per chunk and no extra activation read.
+// d3: the 3x3 layer (cout 32, bf16 in/out, bias + ReLU, optional bit-mask output); dl: the lff conv (cout 64, cin = d3.cin
+// + 32 over the same buffer; epilogue alpha / residual / output as described by dl).  8x32-pixel tiles, 4 waves.
+__global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3, const nvq_conv_desc dl, int tilesX,
+                                                          int tilesY, int nkc, int vec3, int vecl) {
+    constexpr int NB = 2, NT = 32, KS = 3, TAPS = 9, NBL = 4, NTL = 64;
+    constexpr int HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;
+    constexpr int WS3 = ws_stride_halfs(TAPS, NT);            // 10240 halfs
+    constexpr int WSL = ws_stride_halfs(1, NTL);              // 2048 halfs
+    constexpr int XITEMS = NPIX * 4;
+    constexpr int XPER = (XITEMS + 255) / 256;                // 6
+    constexpr int WPER = WS3 / 8 / 256;                       // 5
+    constexpr int T4S = 40;                                   // halfs per pixel of the staged y4 tile (80 B)
+    static_assert(WSL / 8 == 256, "one lff weight piece per thread");
+    static_assert(TH * TW * T4S <= WS3, "the y4 tile reuses the 3x3 weight stage");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS3 + WSL];
+    __bf16* xs = lds;
+    __bf16* ws = lds + NPIX * XSB;
+    __bf16* wl = ws + WS3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int H = d3.h, W = d3.w;
+
+    f32x4 acc[NB][4], lacc[NBL][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NBL; ++a) lacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const u32x4* w3p = reinterpret_cast<const u32x4*>(d3.wpack);
+    const u32x4* wlp = reinterpret_cast<const u32x4*>(dl.wpack);
+    const __bf16* in16 = reinterpret_cast<const __bf16*>(d3.in) + d3.in_coff;
+
+    unsigned xoff[XPER];
+    bool xok[XPER];
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+        const int item = tid + k * 256;
+        const int hp = item >> 2;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+        xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xoff[k] = (xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d3.in_ld) : 0u) + 8 * (item & 3);
+    }
+    u32x4 xr[XPER], wr[WPER], lr;
+    auto fetch = [&](int kc) {                                // raw loads only (d3.cin % 32 == 0: no channel masks)
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + (xoff[k] + kc * KCB));
+#pragma unroll
+        for (int k = 0; k < WPER; ++k) wr[k] = w3p[(size_t)kc * (WS3 / 8) + tid + k * 256];
+        lr = wlp[(size_t)kc * (WSL / 8) + tid];
+    };
+    auto fetch_tail = [&]() { lr = wlp[(size_t)nkc * (WSL / 8) + tid]; };   // lff weights of the y4 channels
+    auto commit = [&]() {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int item = tid + k * 256;
+            if (item < XITEMS) *reinterpret_cast<u32x4*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = xok[k] ? xr[k] : z;
+        }
+#pragma unroll
+        for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
+        reinterpret_cast<u32x4*>(wl)[tid] = lr;
+    };
+    auto ldL = [&](int cb) -> bf16x8 {                       // lff weights: m = cout cb*16 + c, k = channel 8g..
+        return *reinterpret_cast<const bf16x8*>(wl + (g * NTL + cb * 16 + c) * 8);
+    };
+
+    fetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (kc + 1 < nkc) fetch(kc + 1);
+        else fetch_tail();
+        auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
+        };
+        auto ldW = [&](int tap, int cb) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+        };
+        bf16x8 lo[2], hi[2], wa[NB], wn[NB];
+        lo[0] = ldP(0, 0, 0); lo[1] = ldP(0, 1, 0);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) wa[cb] = ldW(0, cb);
+        hi[0] = ldP(1, 0, 0); hi[1] = ldP(1, 1, 0);
+#pragma unroll
+        for (int s = 0; s < TAPS; ++s) {                      // dx-major, dy-minor (see conv_bf16_kernel)
+            const int dy = s % KS;
+            const bool last = s + 1 == TAPS;
+            const int ndx = (s + 1) / KS, ndy = (s + 1) % KS;
+            const bool same_dx = !last && ndy != 0;
+            bf16x8 nlo[2], nhi[2];
+            if (!last) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) wn[cb] = ldW(ndy * KS + ndx, cb);
+            }
+            if (s == 4) {                                     // centre tap: lo / hi are the tile's own pixels (rows 0 / 1)
+#pragma unroll
+                for (int cb = 0; cb < NBL; ++cb) {
+                    const bf16x8 wf = ldL(cb);
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) {
+                        lacc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lo[xh], lacc[cb][xh], 0, 0, 0);
+                        lacc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hi[xh], lacc[cb][2 + xh], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb)
+                    acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], lo[xh], acc[cb][xh], 0, 0, 0);
+                if (same_dx) nhi[xh] = ldP(dy + 2, xh, ndx);
+                else if (!last) nlo[xh] = ldP(0, xh, ndx);
+            }
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb)
+                    acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], hi[xh], acc[cb][2 + xh], 0, 0, 0);
+                if (same_dx) nlo[xh] = hi[xh];
+                else if (!last) nhi[xh] = ldP(1, xh, ndx);
+            }
+            if (!last) {
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) { lo[xh] = nlo[xh]; hi[xh] = nhi[xh]; }
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) wa[cb] = wn[cb];
+            }
+        }
+    }
+    // ---- y4 = relu(acc + bias) as bf16: (a) to the concat buffer through the regular epilogue, (b) into LDS as the 1x1's
+    // last operand.  Lane (c, g) holds channels cb*16 + 4g..+3 of pixel (row 2*wave + (pb>>1), x = (pb&1)*16 + c).
+    __syncthreads();                                          // every wave is done with xs / ws / wl
+    reinterpret_cast<u32x4*>(wl)[tid] = lr;                   // lff weights of channels [cin, cin + 32)
+    __bf16* t4 = ws;                                          // [8 x 32 px][T4S]
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int px = (2 * wave + (pb >> 1)) * TW + (pb & 1) * 16 + c;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int co = cb * 16 + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[cb][pb][e] + (d3.bias ? d3.bias[co + e] : 0.f);
+                if (d3.relu) v[e] = fmaxf(v[e], 0.f);
+                v[e] *= d3.alpha;
+            }
+            *reinterpret_cast<bf16x4*>(t4 + px * T4S + co) = cvt4(make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NBL; ++cb) {
+        const bf16x8 wf = ldL(cb);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int px = (2 * wave + (pb >> 1)) * TW + (pb & 1) * 16 + c;
+            const bf16x8 yf = *reinterpret_cast<const bf16x8*>(t4 + px * T4S + 8 * g);
+            lacc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf, lacc[cb][pb], 0, 0, 0);
+        }
+    }
+    conv_epilogue<NB>(d3, acc, n, ty, tx, 0, wave, c, g, vec3);
+    conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
+}
+
 // ---------------------------------------------------------------- weight gradient
 // grid = (pixel split, ci chunk, 32-co chunk); K = the 32 pixels of one tile row per MFMA.  The LDS images stay
 // [pixel][channels]; ds_read_b64_tr_b16 delivers, per 16-lane group, 4 pixels x 16 channels transposed, i.e.
@@ -498,6 +681,14 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     }
 #undef NVQ_LAUNCH_CONVB
     return check_launch("conv_forward_bf16");
+}
+
+int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {
+    const int tilesX = (d3.w + TW - 1) / TW, tilesY = (d3.h + TH - 1) / TH;
+    const int nkc = d3.cin / KCB;
+    hipLaunchKernelGGL(rdb_tail_kernel, dim3((unsigned)((long)tilesX * tilesY * d3.n)), dim3(256), 0, s, d3, dl, tilesX,
+                       tilesY, nkc, vec3, vecl);
+    return check_launch("rdb_tail_forward");
 }
 
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,

@@ -21,6 +21,7 @@ int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, i
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s);
+int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s);
 
 // Bias-gradient partials of the wgrad kernels: every thread holds the column sums of the dy pieces it staged
 // (channels 4*(tid&7)..+3 of its co chunk).  The 32 threads that share tid&7 are summed through LDS and the

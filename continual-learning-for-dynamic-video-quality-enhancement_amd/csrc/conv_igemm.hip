@@ -421,6 +421,36 @@ int nvq_debug_set_conv_mode(int mode) { set_conv_debug_mode(mode); return NVQ_OK
 size_t nvq_sizeof_conv_desc(void) { return sizeof(nvq_conv_desc); }
 size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }
 
+static int epilogue_vec_ok(const nvq_conv_desc& d) {
+    int v = d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && d.cout_store % 4 == 0 && aligned16(d.out) && (d.cout % 4 == 0 || !d.bias);
+    if (d.bias && !aligned16(d.bias)) v = 0;
+    if (d.out2 && !(d.out2_ld % 4 == 0 && d.out2_coff % 4 == 0 && aligned16(d.out2))) v = 0;
+    if (d.res && !(d.res_ld % 4 == 0 && d.res_coff % 4 == 0 && d.res_cmax % 4 == 0 && aligned16(d.res))) v = 0;
+    if (d.mask && !(d.mask_ld % 4 == 0 && d.mask_coff % 4 == 0 && d.mask_c0 % 4 == 0 && d.mask_c1 % 4 == 0 && aligned16(d.mask))) v = 0;
+    return v;
+}
+
+int nvq_rdb_tail_forward(const nvq_conv_desc* d3p, const nvq_conv_desc* dlp, void* stream) {
+    const nvq_conv_desc d3 = *d3p, dl = *dlp;
+    NVQ_REQUIRE(d3.math == NVQ_MATH_BF16 && dl.math == NVQ_MATH_BF16 && d3.in_bf16 && dl.in_bf16,
+                "rdb_tail_forward: NVQ_MATH_BF16 with a bf16 concat buffer only");
+    NVQ_REQUIRE(d3.ksize == 3 && dl.ksize == 1 && d3.cout == 32 && d3.cout_store == 32 && dl.cout == 64 && dl.cout_store == 64,
+                "rdb_tail_forward: 3x3 -> 32 channels followed by 1x1 -> 64 channels");
+    NVQ_REQUIRE(d3.cin % 32 == 0 && dl.cin == d3.cin + 32 && dl.in == d3.in && dl.in_ld == d3.in_ld && dl.in_coff == d3.in_coff &&
+                    d3.out == (float*)d3.in && d3.out_ld == d3.in_ld && d3.out_coff == d3.in_coff + d3.cin && d3.out_bf16,
+                "rdb_tail_forward: the 3x3 layer must write channels [cin, cin+32) of the buffer both convs read");
+    NVQ_REQUIRE(d3.n == dl.n && d3.h == dl.h && d3.w == dl.w && d3.n > 0 && d3.h > 0 && d3.w > 0, "rdb_tail_forward: shapes");
+    NVQ_REQUIRE(d3.in_ld % 8 == 0 && d3.in_coff % 8 == 0 && aligned16(d3.in) && aligned16(d3.wpack) && aligned16(dl.wpack),
+                "rdb_tail_forward: alignment");
+    NVQ_REQUIRE(!d3.res && !d3.out2 && !d3.mask && !d3.accumulate && d3.bits_mode != 2 && !dl.bits_mode && !dl.mask && !dl.accumulate,
+                "rdb_tail_forward: unsupported epilogue");
+    NVQ_REQUIRE(!d3.bias || aligned16(d3.bias), "rdb_tail_forward: bias alignment");
+    const int vec3 = epilogue_vec_ok(d3), vecl = epilogue_vec_ok(dl);
+    NVQ_REQUIRE(vec3 && vecl, "rdb_tail_forward: the epilogues must be 16-byte addressable");
+    NVQ_REQUIRE(!d3.bits_mode || d3.bits, "rdb_tail_forward: bits");
+    return rdb_tail_bf16(d3, dl, vec3, vecl, (hipStream_t)stream);
+}
+
 int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     const nvq_conv_desc d = *dp;
     NVQ_REQUIRE(d.math == NVQ_MATH_F32 || d.math == NVQ_MATH_BF16, "conv_forward: math mode %d", d.math);

@@ -187,17 +187,26 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     # bf16 mode: the dense layers also emit their ReLU masks as one bit per channel (4 B per pixel) for the backward
     use_bits = training and act_dtype == torch.bfloat16
     sv.bits = [[_new(dev, B, H, W, dtype=torch.int32) for _ in range(LAYERS)] for _ in range(nblocks)] if use_bits else None
+    fuse_tail = act_dtype == torch.bfloat16 and F == 64      # last dense layer + lff in one pass over the concat buffer
     for k in range(nblocks):
         cat = cats[k]
-        for i in range(LAYERS):
+        for i in range(LAYERS - 1 if fuse_tail else LAYERS):
             cin = F + GROWTH * i
             wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
             K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
                            Sl(cat, GROWTH, cin), 3, relu=True, math=math,
                            bits=sv.bits[k][i] if use_bits else None, bits_mode=1 if use_bits else 0)
-        wp = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
-        K.conv_forward(Sl(cat, g.CAT, 0), wp, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
-                       res=Sl(cat, F, 0), math=math)
+        wl = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
+        if fuse_tail:
+            i = LAYERS - 1
+            cin = F + GROWTH * i
+            w3 = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
+            K.rdb_tail_forward(Sl(cat, cin, 0), w3, P[f"residual_blocks.{k}.layers.{i}.0.bias"], Sl(cat, GROWTH, cin), wl,
+                               P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), alpha=0.2, res=Sl(cat, F, 0),
+                               bits=sv.bits[k][i] if use_bits else None)
+        else:
+            K.conv_forward(Sl(cat, g.CAT, 0), wl, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
+                           res=Sl(cat, F, 0), math=math)
 
     # ---- global fusion + upsampler tail
     fused, gr = _new(dev, B, H, W, F), _new(dev, B, H, W, F)

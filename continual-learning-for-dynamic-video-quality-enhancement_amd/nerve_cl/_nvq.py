@@ -74,6 +74,7 @@ SIGNATURES = {
     "nvq_conv_pack_floats": (sz, [ci, ci, ci, ci]),
     "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
+    "nvq_rdb_tail_forward": (ci, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp]),
     "nvq_debug_set_conv_mode": (ci, [ci]),
     "nvq_rdb_backward_weights_floats": (sz, [ci]),
     "nvq_rdb_backward_weights": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp]),
@@ -268,15 +269,14 @@ def conv_pack(w: torch.Tensor, transpose: bool, cin_store: int, cout_keep: Optio
     return wp
 
 
-def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl, ksize: int, *,
+def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl, ksize: int, *,
                  relu: bool = False, alpha: float = 1.0, accumulate: bool = False,
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
-                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> None:
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> ConvDesc:
     """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask."""
     n, h, w, _ = x.t.shape
-    ev0 = TIMER.start() if TIMER is not None else None
     assert out.t.shape[:3] == x.t.shape[:3]
     d = ConvDesc()
     d.inp, d.in_ld, d.in_coff, d.cin = ptr(x.t), x.ld, x.coff, x.c
@@ -299,6 +299,20 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
     if bits_mode:
         assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape) == (n, h, w) and bits.is_contiguous()
         d.bits, d.bits_mode = ptr(bits), bits_mode
+    return d
+
+
+def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl, ksize: int, *,
+                 relu: bool = False, alpha: float = 1.0, accumulate: bool = False,
+                 cout_store: Optional[int] = None, out2: Optional[Sl] = None,
+                 res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
+                 mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> None:
+    n, h, w, _ = x.t.shape
+    ev0 = TIMER.start() if TIMER is not None else None
+    d = _conv_desc(x, wpack, bias, out, ksize, relu=relu, alpha=alpha, accumulate=accumulate, cout_store=cout_store,
+                   out2=out2, res=res, mask=mask, mask_c0=mask_c0, mask_c1=mask_c1, math=math, bits=bits,
+                   bits_mode=bits_mode)
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
     if ev0 is not None:
         cin = x.c if alg_cin is None else alg_cin
@@ -311,6 +325,23 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
                    + (" acc" if accumulate else "")
                    + (" res" if res is not None else "") + (" mask" if mask is not None else "")
                    + (" bitsW" if bits_mode == 1 else " bitsR" if bits_mode == 2 else ""))
+
+
+def rdb_tail_forward(x: Sl, w3: torch.Tensor, b3, y4: Sl, wl: torch.Tensor, bl, out: Sl, *, alpha: float, res: Sl,
+                     bits: Optional[torch.Tensor] = None) -> None:
+    """Last dense layer (3x3, x -> y4 = the next 32 channels of the same buffer, bias + ReLU) and the block's 1x1 fusion
+    over [x | y4] (-> out = alpha * (lff + bias) + res) in one launch (nvq_rdb_tail_forward)."""
+    n, h, w, _ = x.t.shape
+    ev0 = TIMER.start() if TIMER is not None else None
+    d3 = _conv_desc(x, w3, b3, y4, 3, relu=True, math=MATH_BF16, bits=bits, bits_mode=1 if bits is not None else 0)
+    xl = Sl(x.t, x.c + y4.c, x.coff)
+    dl = _conv_desc(xl, wl, bl, out, 1, alpha=alpha, res=res, math=MATH_BF16)
+    check(lib().nvq_rdb_tail_forward(C.byref(d3), C.byref(dl), stream()), "nvq_rdb_tail_forward")
+    if ev0 is not None:
+        esz = lambda sl: 2.0 if sl.bf16 else 4.0   # noqa: E731
+        TIMER.stop(ev0, "rdb_tail_kernel", 2.0 * n * h * w * (x.c * y4.c * 9 + xl.c * out.c),
+                   n * h * w * (x.c * 2.0 + y4.c * 2.0 + res.c * esz(res) + out.c * esz(out)),
+                   f"n{n} cin{x.c}h -> 32 + lff {xl.c} -> {out.c}{'h' if out.bf16 else ''}")
 
 
 def rdb_backward_weights(lff: torch.Tensor, ws: Sequence[torch.Tensor], F: int):

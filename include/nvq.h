@@ -93,6 +93,12 @@ typedef struct nvq_conv_desc {
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
 int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
+/* Tail of ResidualDenseBlock.forward (super_resolution.py:245-253) in one launch: d3 = the last dense layer
+ * (3x3, cin = F+128 -> 32 channels written in place at [cin, cin+32) of the bf16 concat buffer, bias + ReLU, optional
+ * bits_mode 1), dl = the local feature fusion (1x1 over channels [0, cin+32) of the same buffer -> 64 channels, with
+ * dl's alpha / res / out2 / output).  Same results as nvq_conv_forward(d3) followed by nvq_conv_forward(dl); the concat
+ * buffer is read once instead of twice.  NVQ_MATH_BF16 only. */
+int nvq_rdb_tail_forward(const nvq_conv_desc* d3, const nvq_conv_desc* dl, void* stream);
 /* Diagnostics only (tools/kernel_phases.py): 0 = normal; 1 = bf16 conv kernels skip the MFMA section;
  * 2 = they skip the per-chunk global loads after the first chunk.  Results are wrong for mode != 0. */
 int nvq_debug_set_conv_mode(int mode);

@@ -771,3 +771,32 @@ def test_head_gradient_through_matrix_core_wgrad(K):
     dw, db = torch.empty(Fc, 3, 3, 3, device="cuda"), torch.empty(Fc, device="cuda")
     K.conv_wgrad(K.Sl(img8), 3, K.Sl(dx), dw, db, ws_tensor(K), 3, math=K.MATH_BF16)
     assert rel(dw, w.grad) < TOL and rel(db, b.grad) < TOL
+
+
+@pytest.mark.parametrize("N,H,W,out16", [(2, 19, 37, True), (1, 8, 64, False)])
+def test_rdb_tail_forward_fused(K, N, H, W, out16):
+    """nvq_rdb_tail_forward = last dense 3x3 layer (in place, + bit masks) followed by the 1x1 lff with 0.2 scaling and
+    residual: same results as the two separate launches."""
+    Fc, cin, ld = 64, 192, 256
+    cat = bf(rnd(N, ld, H, W))
+    w3, b3 = rnd(32, cin, 3, 3, scale=0.1), rnd(32)
+    wl, bl = rnd(Fc, cin + 32, 1, 1, scale=0.1, seed=3), rnd(Fc, seed=4)
+    w3p = K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16)
+    wlp = K.conv_pack(wl.cuda(), False, cin + 32, math=K.MATH_BF16)
+    odt = torch.bfloat16 if out16 else torch.float32
+    a, b = to_nhwc_bf16(cat), to_nhwc_bf16(cat)
+    oa = torch.zeros(N, H, W, ld if out16 else Fc, device="cuda", dtype=odt)
+    ob = torch.zeros_like(oa)
+    bits_a = torch.zeros(N, H, W, dtype=torch.int32, device="cuda")
+    bits_b = torch.zeros_like(bits_a)
+    K.conv_forward(K.Sl(a, cin, 0), w3p, b3.cuda(), K.Sl(a, 32, cin), 3, relu=True, math=K.MATH_BF16, bits=bits_a, bits_mode=1)
+    K.conv_forward(K.Sl(a, cin + 32, 0), wlp, bl.cuda(), K.Sl(oa, Fc, 0), 1, alpha=0.2, res=K.Sl(a, Fc, 0), math=K.MATH_BF16)
+    K.rdb_tail_forward(K.Sl(b, cin, 0), w3p, b3.cuda(), K.Sl(b, 32, cin), wlp, bl.cuda(), K.Sl(ob, Fc, 0), alpha=0.2,
+                       res=K.Sl(b, Fc, 0), bits=bits_b)
+    assert torch.equal(a, b) and torch.equal(bits_a, bits_b)
+    assert rel(ob.float(), oa.float()) < (5e-3 if out16 else 1e-6)
+    # and against the fp32 reference of the two ops on the bf16-rounded data
+    y4 = F.relu(F.conv2d(cat[:, :cin], bf(w3), b3, padding=1))
+    full = torch.cat([cat[:, :cin], bf(y4)], 1)
+    ref = 0.2 * F.conv2d(full, bf(wl), bl) + cat[:, :Fc]
+    assert rel(from_nhwc(ob.float(), Fc), ref) < 5e-3
