@@ -317,6 +317,158 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------- warp backward without atomics (gather form)
+// The scatter kernel above issues 4 float atomics per (pixel, channel); on gfx950 they execute at the memory side (2 GB of
+// atomic traffic per call at 540p x 4 images, 1.6 ms) and make the feature gradient order-dependent.  Two passes instead:
+//   src pass (per source pixel p): geometry once, the flow gradient (needs feat at the 4 corners), and a 20-byte record
+//     {code = corner offset (y0 - y, x0 - x), w[4] = the 4 bilinear weights, 0 where the corner is outside};
+//   gather pass (per destination pixel q): q receives w_k(p) * dout[p] from every p in the 9x9 window around it whose corner
+//     k is q - found by scanning the window's records (staged in LDS) for  q - p - offset(p) in {0,1}^2.  Fixed summation
+//     order => deterministic.
+// A source whose corner offset falls outside [-4, 3] (|flow| >= 4 px) cannot be found by the window: the src pass scatters
+// it with atomics as before and writes a zero record, so the result is complete for any flow.
+constexpr int WG_R = 4;                         // window radius of the gather pass
+constexpr int WG_TH = 8, WG_TW = 32;            // destination tile
+constexpr int WG_HH = WG_TH + 2 * WG_R, WG_HW = WG_TW + 2 * WG_R;   // 16 x 40 records
+
+// 16 lanes per pixel x float4 = 64 channels per pass (C % 4 == 0; lanes with c4*4 >= C idle; C > 64: channel loop)
+__global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
+                                                           const float* __restrict__ feat, int feat_ld,
+                                                           const float* __restrict__ flow, int flow_ld, int C, int H, int W,
+                                                           float* __restrict__ dfeat, int dfeat_ld,
+                                                           float* __restrict__ dflow, int dflow_ld,
+                                                           float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    const long pix = gid >> 4;
+    if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
+    const int c4 = gid & 15;
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const long img = pix - ((long)y * W + x);
+    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+    const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
+    const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
+    const int ox = g.x0 - x, oy = g.y0 - y;
+    const bool any = g.vnw || g.vne || g.vsw || g.vse;
+    const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
+    const bool scatter = any && !near;
+    float gix = 0.f, giy = 0.f;
+    for (int ch = 4 * c4; ch < C; ch += 64) {
+        const float4 go = ld4(dout + pix * dout_ld + dout_coff + ch);
+        auto corner = [&](bool valid, long o, float wgt, float sx, float sy) {
+            if (!valid) return;
+            const float4 f = ld4(feat + o * feat_ld + ch);
+            const float dsum = f.x * go.x + f.y * go.y + f.z * go.z + f.w * go.w;
+            gix += sx * dsum;
+            giy += sy * dsum;
+            if (scatter) {
+                float* db = dfeat + o * dfeat_ld + ch;
+                atomicAdd(db, go.x * wgt); atomicAdd(db + 1, go.y * wgt); atomicAdd(db + 2, go.z * wgt); atomicAdd(db + 3, go.w * wgt);
+            }
+        };
+        corner(g.vnw, img + (long)g.y0 * W + g.x0, g.wnw, -(y_se - g.iy), -(x_se - g.ix));
+        corner(g.vne, img + (long)g.y0 * W + g.x0 + 1, g.wne, (y_se - g.iy), -(g.ix - fx0));
+        corner(g.vsw, img + (long)(g.y0 + 1) * W + g.x0, g.wsw, -(g.iy - fy0), (x_se - g.ix));
+        corner(g.vse, img + (long)(g.y0 + 1) * W + g.x0 + 1, g.wse, (g.iy - fy0), (g.ix - fx0));
+    }
+    gix = group_sum(gix, 16);
+    giy = group_sum(giy, 16);
+    if (c4 == 0) {
+        const float gx = 2.0f * ((gix * ((float)(W - 1) / 2.f)) / (float)(W - 1));
+        const float gyv = 2.0f * ((giy * ((float)(H - 1) / 2.f)) / (float)(H - 1));
+        float* dp = dflow + pix * dflow_ld;
+        dp[0] = gx;
+        dp[1] = gyv;
+        for (int k = 2; k < dflow_ld; ++k) dp[k] = 0.f;
+        const bool rec = any && near;
+        rec_w[pix] = rec ? make_float4(g.vnw ? g.wnw : 0.f, g.vne ? g.wne : 0.f, g.vsw ? g.wsw : 0.f, g.vse ? g.wse : 0.f)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        rec_code[pix] = rec ? ((oy + WG_R) << 4) | (ox + WG_R) : -1;
+    }
+}
+
+// grid = destination tiles of 8 x 32 pixels.  Phase 1: thread = one destination pixel, scans its 9x9 window of records and
+// lists the contributing sources (window index, weight) in LDS.  Phase 2: 16 lanes per pixel (one float4 of channels
+// each, so a pixel's 64 channels are one coalesced 256-byte access) walk the lists and add into dfeat.
+constexpr int WG_MAXHIT = 12;                   // list length per pixel; further hits (a strongly contracting flow) are
+                                                // applied by phase 1 itself, one pixel per lane
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
+                                                              const float4* __restrict__ rec_w,
+                                                              const int* __restrict__ rec_code, int C, int H, int W,
+                                                              int tilesX, int tilesY, float* __restrict__ dfeat,
+                                                              int dfeat_ld) {
+    __shared__ float4 lw[WG_HH * WG_HW];
+    __shared__ int lc[WG_HH * WG_HW];
+    __shared__ int hit_n[WG_TH * WG_TW];
+    __shared__ int hit_p[WG_TH * WG_TW * WG_MAXHIT];        // source pixel, relative: (sy + R) * 16 + (sx + R)
+    __shared__ float hit_w[WG_TH * WG_TW * WG_MAXHIT];
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    for (int i = threadIdx.x; i < WG_HH * WG_HW; i += 256) {
+        const int hy = i / WG_HW, hx = i - hy * WG_HW;
+        const int gy = ty * WG_TH + hy - WG_R, gx = tx * WG_TW + hx - WG_R;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const long pp = ok ? (long)(n * H + gy) * W + gx : 0;
+        lc[i] = ok ? rec_code[pp] : -1;
+        lw[i] = ok ? rec_w[pp] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {   // ---- phase 1
+        const int ly = threadIdx.x / WG_TW, lx = threadIdx.x % WG_TW;
+        const int qy = ty * WG_TH + ly, qx = tx * WG_TW + lx;
+        int cnt = 0;
+        if (qy < H && qx < W) {
+            for (int sy = -WG_R; sy <= WG_R; ++sy)
+                for (int sx = -WG_R; sx <= WG_R; ++sx) {
+                    const int hi = (ly + WG_R + sy) * WG_HW + lx + WG_R + sx;
+                    const int code = lc[hi];
+                    if (code < 0) continue;
+                    const int a = -sy - ((code >> 4) - WG_R), b = -sx - ((code & 15) - WG_R);   // q - p - offset(p)
+                    if ((unsigned)a > 1u || (unsigned)b > 1u) continue;
+                    const float4 w4 = lw[hi];
+                    const float wgt = a == 0 ? (b == 0 ? w4.x : w4.y) : (b == 0 ? w4.z : w4.w);
+                    if (wgt == 0.f) continue;
+                    if (cnt < WG_MAXHIT) {
+                        hit_p[threadIdx.x * WG_MAXHIT + cnt] = ((sy + WG_R) << 4) | (sx + WG_R);
+                        hit_w[threadIdx.x * WG_MAXHIT + cnt] = wgt;
+                        ++cnt;
+                    } else {                                  // overflow: apply directly (still no atomics: q is ours)
+                        const float* src = dout + ((long)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff;
+                        float* dst = dfeat + ((long)(n * H + qy) * W + qx) * dfeat_ld;
+                        for (int ch = 0; ch < C; ++ch) dst[ch] += wgt * src[ch];
+                    }
+                }
+        }
+        hit_n[threadIdx.x] = cnt;
+    }
+    __syncthreads();
+    // ---- phase 2
+    const int c4 = threadIdx.x & 15;
+    for (int qi = threadIdx.x >> 4; qi < WG_TH * WG_TW; qi += 16) {
+        const int cnt = hit_n[qi];
+        if (cnt == 0) continue;                               // (uniform over the 16 lanes of the pixel)
+        const int ly = qi / WG_TW, lx = qi % WG_TW;
+        const int qy = ty * WG_TH + ly, qx = tx * WG_TW + lx;
+        const long qpix = (long)(n * H + qy) * W + qx;
+        for (int ch = 4 * c4; ch < C; ch += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < cnt; ++k) {
+                const int hp = hit_p[qi * WG_MAXHIT + k];
+                const float wgt = hit_w[qi * WG_MAXHIT + k];
+                const int sy = (hp >> 4) - WG_R, sx = (hp & 15) - WG_R;
+                const float4 v = ld4(dout + ((long)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff + ch);
+                acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+            }
+            float* dst = dfeat + qpix * dfeat_ld + ch;
+            float4 o = ld4(dst);
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            st4(dst, o);
+        }
+    }
+}
+
 // NVQ_MATH_BF16 variants (corr_mfma.hip)
 bool corr_mfma_supported(int C);
 int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C, int N, int H, int W,
@@ -382,9 +534,27 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
-                      float* dflow, int dflow_ld, void* stream) {
+                      float* dflow, int dflow_ld, float* records, size_t records_bytes, void* stream) {
     NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
     NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
+    if (records) {                                            // gather form (deterministic, no atomics for |flow| < 4 px)
+        const long npix = (long)N * H * W;
+        NVQ_REQUIRE(records_bytes >= (size_t)npix * 20 && aligned16(records), "warp_backward: records buffer needs 20 B per pixel");
+        NVQ_REQUIRE(dout_ld % 4 == 0 && dout_coff % 4 == 0 && feat_ld % 4 == 0 && dfeat_ld % 4 == 0 && aligned16(dout) &&
+                        aligned16(feat) && aligned16(dfeat),
+                    "warp_backward: alignment");
+        float4* rec_w = reinterpret_cast<float4*>(records);
+        int* rec_code = reinterpret_cast<int*>(rec_w + npix);
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(warp_bwd_src_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, feat,
+                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix);
+        int rc = check_launch("warp_backward(src)");
+        if (rc) return rc;
+        const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;
+        hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout, dout_ld,
+                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld);
+        return check_launch("warp_backward(gather)");
+    }
     const long total = (long)N * H * W * (C < 64 ? C : 64);
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
                        dout_coff, feat, feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, total);

@@ -291,8 +291,12 @@ def test_correlation_forward_backward(K, C, B, R, H, W):
     assert rel(from_nhwc(dx2), x2.grad) < TOL
 
 
-@pytest.mark.parametrize("C,N,H,W,mag", [(32, 2, 9, 14, 1.5), (64, 1, 11, 37, 4.0), (16, 1, 6, 7, 30.0)])
-def test_warp_forward_backward(K, C, N, H, W, mag):
+@pytest.mark.parametrize("gather", [True, False])
+@pytest.mark.parametrize("C,N,H,W,mag", [(32, 2, 9, 14, 1.5), (64, 1, 11, 37, 4.0), (16, 1, 6, 7, 30.0), (64, 2, 19, 45, 0.8),
+                                         (128, 1, 9, 33, 6.0)])
+def test_warp_forward_backward(K, C, N, H, W, mag, gather):
+    """gather=True: the atomics-free two-pass backward (flows up to 30 px exercise its scatter fallback and the image border);
+    gather=False: the scatter form."""
     feat = rnd(N, C, H, W).requires_grad_()
     flow = (rnd(N, 2, H, W, seed=2) * mag).requires_grad_()
     out = sr_oracle.warp(feat, flow)
@@ -306,8 +310,10 @@ def test_warp_forward_backward(K, C, N, H, W, mag):
     dal = to_nhwc(dy, 3 * C, 2 * C)
     dfeat = torch.zeros(N, H, W, C, device="cuda")
     dflow = torch.full((N, H, W, 4), 9.0, device="cuda")
-    K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat), dflow)
-    assert rel(from_nhwc(dfeat), feat.grad) < 5e-5
+    dfeat = to_nhwc(rnd(N, C, H, W, seed=8))              # the gradient is ADDED to what is there
+    base = from_nhwc(dfeat)
+    K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat), dflow, gather=gather)
+    assert rel(from_nhwc(dfeat) - base, feat.grad) < 5e-5
     assert rel(from_nhwc(dflow, 2), flow.grad) < 2e-4
     assert dflow[..., 2:].abs().max().item() == 0
 
