@@ -221,7 +221,9 @@ def main():
                       "kernel": name, "launches": d["launches"],
                       "avg_launch_ms": d["ms_total"] / d["launches"],
                       "share_of_step": d["ms_total"] / (dt_b * 1e3),
-                      "measured": "second pass of the same K steps with a HIP event pair around each conv launch"}
+                      "measured": "second pass of the same K steps with a HIP event pair around each conv launch; "
+                                  f"{getattr(timer, 'outliers', 0)} of {len(timer.records)} pairs that also caught a host launch "
+                                  "gap (> 2x the median of their shape) counted at that median"}
             if args.math == "f32":      # exact-fp32 MFMA: compute-bound (157 TF vs 8 TB/s => ridge at 20 FLOP/B)
                 roofline = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": tflops / PEAK_F32_MFMA_TFLOPS, "algorithmic_gbs": gbs, **common}

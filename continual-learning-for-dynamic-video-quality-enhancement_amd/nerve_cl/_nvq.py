@@ -217,25 +217,45 @@ class KernelTimer:
         ev1.record()
         self.records.append((label, flops, nbytes, ev0, ev1, shape))
 
+    def _durations(self):
+        """ms per record.  An event pair brackets the launch on the stream, so when the GPU has caught up with the host the
+        pair also contains the host's launch gap; such records (more than twice the median of their (label, shape) group)
+        are counted at the group median.  Returns (durations, number of records replaced)."""
+        raw = [e0.elapsed_time(e1) for _, _, _, e0, e1, _ in self.records]
+        groups = {}
+        for i, (label, _, _, _, _, shape) in enumerate(self.records):
+            groups.setdefault((label, shape), []).append(i)
+        fixed = 0
+        for idx in groups.values():
+            vals = sorted(raw[i] for i in idx)
+            med = vals[len(vals) // 2]
+            for i in idx:
+                if raw[i] > 2.0 * med:
+                    raw[i] = med
+                    fixed += 1
+        self.outliers = fixed
+        return raw
+
     def summary(self):
         """{label: dict(launches, ms_total, flops, bytes)} (call after a device synchronize)."""
         out = {}
-        for label, fl, nb, e0, e1, _ in self.records:
+        dur = self._durations()
+        for (label, fl, nb, _, _, _), ms in zip(self.records, dur):
             d = out.setdefault(label, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
-            d["ms_total"] += e0.elapsed_time(e1)
+            d["ms_total"] += ms
             d["flops"] += fl
             d["bytes"] += nb
         return out
 
-
     def by_shape(self):
         """{(label, shape): dict(...)} for the per-shape table of bench.py --detail."""
         out = {}
-        for label, fl, nb, e0, e1, shape in self.records:
+        dur = self._durations()
+        for (label, fl, nb, _, _, shape), ms in zip(self.records, dur):
             d = out.setdefault((label, shape), dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
-            d["ms_total"] += e0.elapsed_time(e1)
+            d["ms_total"] += ms
             d["flops"] += fl
             d["bytes"] += nb
         return out
