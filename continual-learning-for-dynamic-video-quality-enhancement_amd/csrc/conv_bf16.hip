@@ -448,10 +448,13 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
 // CIC: input channels per workgroup.  32: wave = one 16x16 (ci, co) block for all taps.  64 (bf16 x only): wave =
 // one 16-ci block x both 16-co blocks, i.e. twice the MFMA work per staged dy tile and dy re-read half as often -
 // the per-tile iteration is latency-bound, so doing more per iteration is what pays.
-template <int KS, bool XB, bool YB, int CIC>
+// COC: output channels per workgroup (32, or 64 for the 1x1 kernel with bf16 dy: its accumulators are one fragment per
+// (ci, co) block, so a wave takes all four 16-co blocks and the x tile is fetched once instead of once per 32 co).
+template <int KS, bool XB, bool YB, int CIC, int COC = 32>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc d, int tilesX, int tilesY,
                                                              int ntiles, int nci32, int nco) {
     static_assert(CIC == 32 || (CIC == 64 && XB), "64-channel chunks need bf16 x");
+    static_assert(COC == 32 || (COC == 64 && CIC == 64 && YB && KS == 1), "64-co chunks: 1x1, bf16 x and dy");
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int HW_ = TW + 2 * HALO;
@@ -459,13 +462,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     constexpr int NPIX = HW_ * HH_;
     constexpr int XSX = CIC == 64 ? 80 : XSB;        // bf16 per staged x pixel (160 B / 96 B)
     constexpr int XPP = (XB ? 4 : 8) * (CIC / 32);   // 16-byte pieces per pixel of the X chunk
-    constexpr int YPP = YB ? 4 : 8;
-    constexpr int XCH = CIC / XPP, YCH = 32 / YPP;   // channels per piece
+    constexpr int YSX = COC == 64 ? 80 : XSB;        // bf16 per staged dy pixel
+    constexpr int YPP = (YB ? 4 : 8) * (COC / 32);
+    constexpr int XCH = CIC / XPP, YCH = COC / YPP;   // channels per piece
     constexpr int XITEMS = NPIX * XPP;
     constexpr int XPER = (XITEMS + 255) / 256;
     constexpr int YPER = TH * TW * YPP / 256;
-    constexpr int NCO = CIC == 64 ? 2 : 1;           // co blocks per wave
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSX + TH * TW * XSB];
+    constexpr int NCO = (CIC == 64 ? 2 : 1) * (COC / 32);   // 16-co blocks per wave
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSX + TH * TW * YSX];
     __bf16* xs = lds;
     __bf16* dys = lds + NPIX * XSX;
 
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     const int xq = XCH * (tid & (XPP - 1));          // channel offset of this thread's X pieces inside the chunk
     const int yq = YCH * (tid & (YPP - 1));
     const bool xch_ok = cic * CIC + xq < d.cin;
-    const int ych = coc * WG_C + yq;
+    const int ych = coc * COC + yq;
     const bool ych_ok = ych < d.cout;
     // all loads unconditional (invalid pieces read element 0 of the slice); the validity masks are applied in
     // commit(), so that nothing between the prefetch and the next commit uses a loaded value
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
         for (int k = 0; k < YPER; ++k) {
             const int item = tid + k * 256;
             const u32x4 v = (ymask >> k) & 1 ? yr[k] : z;
-            __bf16* dst = dys + (item / YPP) * XSB + YCH * (item & (YPP - 1));
+            __bf16* dst = dys + (item / YPP) * YSX + YCH * (item & (YPP - 1));
             if constexpr (YB) {
                 *reinterpret_cast<u32x4*>(dst) = v;           // word w holds channels 2w (low half), 2w+1 (high half)
                 bsumA.x += bf_lo(v[0]); bsumA.y += bf_hi(v[0]); bsumA.z += bf_lo(v[1]); bsumA.w += bf_hi(v[1]);
@@ -580,8 +584,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             bf16x8 bfrag[NCO];
 #pragma unroll
             for (int a = 0; a < NCO; ++a) {
-                const s16x4 b0 = tr_read(dys, XSB, py * TW + 4 * g, cob0 + a);
-                const s16x4 b1 = tr_read(dys, XSB, py * TW + 16 + 4 * g, cob0 + a);
+                const s16x4 b0 = tr_read(dys, YSX, py * TW + 4 * g, cob0 + a);
+                const s16x4 b1 = tr_read(dys, YSX, py * TW + 16 + 4 * g, cob0 + a);
                 bfrag[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -601,15 +605,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     // partial slabs are indexed in 32-ci units so the reduce kernel is independent of CIC
     const int slab = cic * (CIC / 32) + (cib * 16) / 32;
     if (slab < nci32) {                                      // wave-uniform
-        float* part = d.workspace + ((size_t)(blockIdx.x * nci32 + slab) * nco + coc) * (TAPS * WG_C * WG_C);
         const int cil0 = (cib * 16) % 32;
 #pragma unroll
-        for (int a = 0; a < NCO; ++a)
+        for (int a = 0; a < NCO; ++a) {
+            // `nco` and the slab index count 32-co chunks: block a of a 64-co workgroup lies in chunk coc*2 + a/2
+            const int coc32 = coc * (COC / 32) + (cob0 + a) / 2, cob = (cob0 + a) % 2;
+            if (coc32 >= nco) continue;
+            float* part = d.workspace + ((size_t)(blockIdx.x * nci32 + slab) * nco + coc32) * (TAPS * WG_C * WG_C);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    part[(tap * WG_C + cil0 + 4 * g + e) * WG_C + (cob0 + a) * 16 + r] = acc[a][tap][e];
+                for (int e = 0; e < 4; ++e) part[(tap * WG_C + cil0 + 4 * g + e) * WG_C + cob * 16 + r] = acc[a][tap][e];
+        }
     }
 
     // bias partials: thread t's sums cover channels yq..yq+YCH-1 of the co chunk, pieces repeat every YPP threads
@@ -619,12 +626,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
         st4(scratch + 8 * tid, bsumA);
         st4(scratch + 8 * tid + 4, bsumB);
         __syncthreads();
-        if (tid < 32) {
+        if (tid < COC) {
             const int piece = tid / YCH, e = tid % YCH;      // channel `tid` of the chunk
             float s = 0.f;
             for (int k = 0; k < 256 / YPP; ++k) s += scratch[8 * (YPP * k + piece) + e];
             float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
-            bp[((size_t)blockIdx.x * nco + coc) * WG_C + tid] = s;
+            const int coc32 = coc * (COC / 32) + tid / WG_C;
+            if (coc32 < nco) bp[((size_t)blockIdx.x * nco + coc32) * WG_C + tid % WG_C] = s;
         }
     }
 }
@@ -701,6 +709,17 @@ int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int t
         if (nsplit < 1) nsplit = 1;
         if (nsplit > ntiles) nsplit = ntiles;
         if (nsplit >= 8) nsplit &= ~7;      // multiple of the XCD count: see xcd_tile()
+    }
+    // 1x1, bf16 x and dy, >= 64 output channels: one workgroup takes 64 co (x fetched once per 64 co instead of per 32)
+    if (wide && d.ksize == 1 && d.cout >= 64) {
+        const int nco64 = (nco + 1) / 2;
+        nsplit = WGRAD_MAX_WG / (ncig * nco64);
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > ntiles) nsplit = ntiles;
+        if (nsplit >= 8) nsplit &= ~7;
+        hipLaunchKernelGGL((wgrad_bf16_kernel<1, true, true, 64, 64>), dim3(nsplit, ncig, nco64), dim3(256), 0, s, d, tilesX,
+                           tilesY, ntiles, nci, nco);
+        return nsplit;
     }
     const dim3 grid(nsplit, ncig, nco);
 #define NVQ_LAUNCH_WG(KS, XB, YB, CIC) \

@@ -569,7 +569,8 @@ def test_conv_bf16_stored_dense_block_epilogues(K):
 
 
 @pytest.mark.parametrize("xb,yb", [(True, True), (True, False), (False, True)])
-@pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 16, 40), (224, 64, 1, 1, 11, 37), (192, 64, 3, 1, 8, 64)])
+@pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 16, 40), (224, 64, 1, 1, 11, 37), (192, 64, 3, 1, 8, 64),
+                                              (96, 72, 1, 2, 9, 33), (64, 128, 1, 1, 17, 32)])
 def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     x, dy = bf(rnd(N, cin, H, W)), bf(rnd(N, cout, H, W, seed=3))
     w = rnd(cout, cin, k, k).requires_grad_()
