@@ -37,7 +37,7 @@ def pmc_traffic(kernel: str, batch: int):
     in two separate passes of this script at the default batch, corrected as MI355X_MICROARCH.md prescribes).
     bench.py cannot collect PMC counters itself; returns None when no matching summary exists."""
     path = os.path.join(REPO, "profiles", "r01_v2_traffic_pmc.json")
-    if batch != 4 or not os.path.exists(path):
+    if batch != 8 or not os.path.exists(path):
         return None
     try:
         blob = json.load(open(path))["kernels"]
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--features", type=int, default=64)

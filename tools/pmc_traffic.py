@@ -24,7 +24,7 @@ def per_kernel(path, counter):
 fetch, names = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --output-format csv -- python3 "
-                  "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer (B=4)",
+                  "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer (default batch 8)",
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 "
                      "(MI355X_MICROARCH.md, HBM)", "kernels": {}}
 for lab in fetch:
