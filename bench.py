@@ -207,6 +207,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     roofline = None
+    residual_stack = None
     kernels = {}
     if timer is not None:
         kernels = timer.summary()
@@ -230,6 +231,17 @@ def main():
             else:                       # bf16 MFMA on fp32-stored activations: HBM-bound
                 roofline = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": gbs / PEAK_HBM_GBS, "algorithmic_tflops": tflops, **common}
+    if timer is not None and kernels:
+        # the residual dense stack as a whole (north-star: >= 40 % of the HBM roofline): every conv / weight-gradient launch
+        # of the 8 dense blocks, forward and backward, algorithmic bytes over measured time
+        rdb = timer.by_tag().get("rdb")
+        if rdb and rdb["ms_total"] > 0:
+            gbs = rdb["bytes"] / (rdb["ms_total"] * 1e-3) / 1e9
+            residual_stack = {"launches_per_step": rdb["launches"] // args.steps,
+                              "ms_per_clip": rdb["ms_total"] / args.steps / B,
+                              "algorithmic_gb_per_clip": rdb["bytes"] / args.steps / B / 1e9,
+                              "achieved_gbs": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                              "tflops": rdb["flops"] / (rdb["ms_total"] * 1e-3) / 1e12}
     if timer is not None and args.detail:
         rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms_total"])
         print("%-24s %-34s %5s %9s %9s %9s" % ("kernel", "shape", "calls", "ms/step", "TFLOP/s", "alg GB/s"), file=sys.stderr)
@@ -249,6 +261,7 @@ def main():
                    "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss,
                    "conv_internal_storage": "bf16" if net.bf16_activations else "f32"},
         "roofline": roofline,
+        "residual_stack": residual_stack,
     }
     if kernels:
         line["ms_per_step_with_kernel_events"] = dt_b / args.steps * 1e3

@@ -184,6 +184,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sv.cats, sv.resout = cats, resout
 
     # ---- residual dense blocks
+    K.TIMER_TAG = "rdb"
     # bf16 mode: the dense layers also emit their ReLU masks as one bit per channel (4 B per pixel) for the backward
     use_bits = training and act_dtype == torch.bfloat16
     sv.bits = [[_new(dev, B, H, W, dtype=torch.int32) for _ in range(LAYERS)] for _ in range(nblocks)] if use_bits else None
@@ -208,6 +209,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             K.conv_forward(Sl(cat, g.CAT, 0), wl, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
                            res=Sl(cat, F, 0), math=math)
 
+    K.TIMER_TAG = ""
     # ---- global fusion + upsampler tail
     fused, gr = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
     K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F, math=math), P["gff.0.bias"], Sl(fused), 3,
@@ -258,6 +260,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     _capture("dres", gout.t[..., :F].float())
 
     # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
+    K.TIMER_TAG = "rdb"
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
@@ -279,6 +282,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                    math=math)
         nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
         K.conv_forward(Sl(dcat, g.CAT, 0), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
+    K.TIMER_TAG = ""
     dprev = Sl(dagg)
 
     _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F].float())

@@ -200,7 +200,8 @@ class KernelTimer:
     """HIP-event timing of individual launches on the current stream (bench.py only)."""
 
     def __init__(self):
-        self.records = []          # (label, flops, bytes, ev0, ev1)
+        self.records = []          # (label, flops, bytes, ev0, ev1, shape)
+        self.tags = []             # section tag of each record (TIMER_TAG at launch time)
         self.enabled = True
 
     def start(self):
@@ -216,6 +217,7 @@ class KernelTimer:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         self.records.append((label, flops, nbytes, ev0, ev1, shape))
+        self.tags.append(TIMER_TAG)
 
     def _durations(self):
         """ms per record.  An event pair brackets the launch on the stream, so when the GPU has caught up with the host the
@@ -248,6 +250,18 @@ class KernelTimer:
             d["bytes"] += nb
         return out
 
+    def by_tag(self):
+        """{tag: dict(launches, ms_total, flops, bytes)} over the engine's section tags (e.g. "rdb")."""
+        out = {}
+        dur = self._durations()
+        for (label, fl, nb, _, _, _), ms, tag in zip(self.records, dur, self.tags):
+            d = out.setdefault(tag, dict(launches=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms_total"] += ms
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
     def by_shape(self):
         """{(label, shape): dict(...)} for the per-shape table of bench.py --detail."""
         out = {}
@@ -262,6 +276,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+TIMER_TAG = ""     # set by the engine around a section (bench.py's per-section roofline)
 
 
 def _nt(cout: int) -> int:

@@ -331,3 +331,28 @@ def test_lightweight_against_reference_fixture_and_oracle(SR, path):
     with torch.no_grad():
         y = eng(x.cuda().unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
         assert torch.equal(y, net.eval()(x.cuda()))
+
+
+def test_lightweight_bf16_mode_runs_close_to_fp32(SR):
+    """LightweightSuperResolution in the bf16 throughput mode (F = 32: the 32-channel kernel variants): forward + backward
+    run and stay close to the fp32 mode."""
+    from nerve_cl import _nvq
+    from nerve_cl.models import LightweightSuperResolution
+    sd = synth.formula_state_light(2, gain=synth.GOLDEN_GAIN)
+    x = synth.formula_clip(2, 1, 40, 56)[:, 0].contiguous().cuda()
+    tgt = synth.formula_target(2, 80, 112).cuda()
+    outs, grads = [], []
+    for bf16 in (False, True):
+        net = LightweightSuperResolution(2)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        if bf16:
+            net.math_mode, net.bf16_activations = _nvq.MATH_BF16, True
+        out = net(x)
+        F.mse_loss(out, tgt).backward()
+        outs.append(out.detach())
+        grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
+    mse = (outs[0] - outs[1]).pow(2).mean().item()
+    assert 10 * np.log10(1.0 / max(mse, 1e-12)) > 40.0
+    cos = F.cosine_similarity(grads[0], grads[1], dim=0).item()
+    assert cos > 0.99, cos
