@@ -658,6 +658,10 @@ int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, i
 }
 
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
+    // the kernels keep per-thread activation offsets as 32-bit element counts
+    NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32),
+                "conv_forward(bf16): input tensor of %d x %d x %d x %d elements exceeds the 32-bit offsets of the kernels", d.n,
+                d.h, d.w, d.in_ld);
     const int NT = choose_nt(d.cout);
     const int ncz = (d.cout_store + NT - 1) / NT;
     const int nkc = (d.cin + KCB - 1) / KCB;
@@ -692,6 +696,7 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
 }
 
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {
+    NVQ_REQUIRE((size_t)d3.n * d3.h * d3.w * d3.in_ld < ((size_t)1 << 32), "rdb_tail_forward: tensor exceeds 32-bit offsets");
     const int tilesX = (d3.w + TW - 1) / TW, tilesY = (d3.h + TH - 1) / TH;
     const int nkc = d3.cin / KCB;
     hipLaunchKernelGGL(rdb_tail_kernel, dim3((unsigned)((long)tilesX * tilesY * d3.n)), dim3(256), 0, s, d3, dl, tilesX,
