@@ -72,29 +72,21 @@ class Saved:
     pass
 
 
-def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: int, scale: int,
-            training: bool, math: int = K.MATH_F32, act_dtype: torch.dtype = torch.float32
-            ) -> "tuple[torch.Tensor, Saved]":
-    """act_dtype: storage type of the conv-internal tensors (dense-block concat buffers, flow-net and attention
-    hidden activations and, in backward, their gradients).  torch.bfloat16 needs math == MATH_BF16; every
-    tensor a non-conv kernel touches stays fp32."""
-    assert act_dtype == torch.float32 or math == K.MATH_BF16
-    g = Geometry(frames, F, nblocks, scale)
+def _extract(P: Dict[str, torch.Tensor], frames: torch.Tensor, slots, F: int, training: bool, math: int,
+             act_dtype: torch.dtype, outA: Sl, split_images: int, outB: Optional[Sl], sv) -> None:
+    """FeatureExtractor.forward (super_resolution.py:40-53) for the T = len(slots) frames of every clip, batched in slot
+    order; the features of the first `split_images` images go to outA, the rest to outB.  Saves what backward needs in sv."""
+    B, _, _, H, W = frames.shape
+    T = len(slots)
+    NI = T * B
     dev = frames.device
-    B, T, H, W, NI, NO, c = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c
     ws = workspace(dev)
-    sv = Saved()
-    sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
-
-    # ---- feature extractor, all T frames in one batch (slot order)
     feat0 = _new(dev, NI, H, W, F, dtype=act_dtype)
     # bf16 mode: the head's weight gradient runs on the matrix cores (conv_wgrad over the frames as bf16 NHWC-8)
     sv.img8 = _new(dev, NI, H, W, 8, dtype=torch.bfloat16) if (training and K.dwconv_bn_fusable(feat0, F)) else None
-    K.head_forward(frames, g.slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0,
+    K.head_forward(frames, slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0,
                    img8=sv.img8)
-    aligned = _new(dev, B, H, W, T * F)
-    feat_oth = _new(dev, max(NO, 1), H, W, F)
-    sv.feat0, sv.aligned, sv.feat_oth = feat0, aligned, feat_oth
+    sv.feat0 = feat0
     sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = [], [], [], [], []
     cur, cur_bn = feat0, None         # cur_bn: BatchNorm + ReLU still to be applied to `cur` (fused into the consumer)
     sv.dw_in = []                     # (tensor, bn) the depthwise conv of layer k was fed with
@@ -109,7 +101,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
         mean, invstd = _new(dev, T, F), _new(dev, T, F)
         if training:
-            K.bn_stats(p, B, [g.slots.index(t) for t in range(T)], mean, invstd,
+            K.bn_stats(p, B, [slots.index(t) for t in range(T)], mean, invstd,
                        P[pre + "bn.running_mean"], P[pre + "bn.running_var"], ws, BN_EPS, BN_MOM)
             P[pre + "bn.num_batches_tracked"].add_(T)
         else:
@@ -121,12 +113,40 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             r, cur_bn = _new(dev, NI, H, W, F, dtype=act_dtype), None
             K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], None, Sl(r), NI)
         else:
-            # features = relu(bn(.)) + head features; centre frame lands in its slot of `aligned`
+            # features = relu(bn(.)) + head features
             r = None
-            K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], feat0,
-                            Sl(aligned, F, c * F), B, Sl(feat_oth) if NO else None)
+            K.bn_apply_relu(p, B, mean, invstd, P[pre + "bn.weight"], P[pre + "bn.bias"], feat0, outA, split_images, outB)
         sv.dws.append(d); sv.pws.append(p); sv.acts.append(r); sv.bn_mean.append(mean); sv.bn_invstd.append(invstd)
         cur = r
+
+
+def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: int, scale: int,
+            training: bool, math: int = K.MATH_F32, act_dtype: torch.dtype = torch.float32,
+            features: Optional[torch.Tensor] = None) -> "tuple[torch.Tensor, Saved]":
+    """act_dtype: storage type of the conv-internal tensors (dense-block concat buffers, flow-net and attention
+    hidden activations and, in backward, their gradients).  torch.bfloat16 needs math == MATH_BF16; every
+    tensor a non-conv kernel touches stays fp32."""
+    assert act_dtype == torch.float32 or math == K.MATH_BF16
+    g = Geometry(frames, F, nblocks, scale)
+    dev = frames.device
+    B, T, H, W, NI, NO, c = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c
+    ws = workspace(dev)
+    sv = Saved()
+    sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
+
+    # ---- feature extractor, all T frames in one batch (slot order)
+    aligned = _new(dev, B, H, W, T * F)
+    feat_oth = _new(dev, max(NO, 1), H, W, F)
+    sv.aligned, sv.feat_oth = aligned, feat_oth
+    if features is None:
+        _extract(P, frames, g.slots, F, training, math, act_dtype, Sl(aligned, F, c * F), B, Sl(feat_oth) if NO else None, sv)
+    else:
+        # inference with cached per-frame features (extract_features), [T,B,H,W,F] in time order: no extractor launches
+        assert not training and tuple(features.shape) == (T, B, H, W, F) and features.dtype == torch.float32
+        sv.feat0 = None                                      # marks the state as not differentiable
+        aligned[..., c * F:(c + 1) * F].copy_(features[c])
+        for j in range(1, T):
+            feat_oth[(j - 1) * B:j * B].copy_(features[g.slots[j]])
     center = Sl(aligned, F, c * F)
 
     # ---- motion: correlation -> flow net -> warp, the T-1 reference frames batched
@@ -230,8 +250,24 @@ def _wgrad(x: Sl, cin_w: int, dy: Sl, G: Dict[str, torch.Tensor], wname: str, bn
     K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math)
 
 
+def extract_features(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, math: int = K.MATH_F32,
+                     act_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Per-frame features of a whole video in eval mode (running BatchNorm statistics): frames (B,Tv,C,H,W) ->
+    [Tv,B,H,W,F] fp32, to be handed to forward(features=...) window by window (EnhancementEngine.enhance_video)."""
+    B, Tv, _, H, W = frames.shape
+    out = _new(frames.device, Tv, B, H, W, F)
+    for t0 in range(0, Tv, K.MAX_T):                         # the kernels take at most MAX_T frame groups per launch
+        n = min(K.MAX_T, Tv - t0)
+        part = frames[:, t0:t0 + n].contiguous()
+        _extract(P, part, list(range(n)), F, False, math, act_dtype, Sl(out[t0:t0 + n].view(n * B, H, W, F)), n * B, None,
+                 Saved())
+    return out
+
+
 def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[str, torch.Tensor]) -> None:
     """Write the gradient of every parameter into G[name] (each exactly once, overwrite)."""
+    if sv.feat0 is None:
+        raise RuntimeError("forward(features=...) is an inference path: its result cannot be differentiated")
     g = sv.g
     dev = dout.device
     B, T, H, W, NI, NO, c, F = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c, g.F

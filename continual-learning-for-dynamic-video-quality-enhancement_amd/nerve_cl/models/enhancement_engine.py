@@ -108,17 +108,35 @@ class EnhancementEngine(nn.Module):
         return results
 
     def enhance_video(self, video: torch.Tensor, corruption_masks: Optional[torch.Tensor] = None,
-                      batch_size: int = 4) -> torch.Tensor:
+                      batch_size: int = 4, cache_features: bool = True) -> torch.Tensor:
         """Sliding-window enhancement of a whole clip, (T,C,H,W) or (B,T,C,H,W) -> same rank, upscaled
-        (reference :186-248: window = 2*max(recovery window, sr window)+1, clipped at the clip boundaries)."""
+        (reference :186-248: window = 2*max(recovery window, sr window)+1, clipped at the clip boundaries).
+        cache_features (eval mode, gradients off, temporal SR net): every frame's features are extracted once for the whole
+        clip instead of once per window that contains it; same results."""
         squeeze = video.dim() == 4
         if squeeze:
             video = video.unsqueeze(0)
         B, T, C, H, W = video.shape
         win = 2 * max(self.config.recovery_temporal_window, self.config.sr_temporal_window) + 1
+        sr = self.super_resolution
+        cached = (cache_features and isinstance(sr, SuperResolutionNet) and not self.training and not torch.is_grad_enabled()
+                  and corruption_masks is None)
+        feats = sr.extract_features(video) if cached else None
         frames_out = []
         for t in range(T):
             lo, hi = max(0, t - win // 2), min(T, t + win // 2 + 1)
+            if cached:
+                # the frames forward() would hand to the SR net: centre +- sr window inside [lo, hi), right-padded
+                w = self.config.sr_temporal_window
+                idx = list(range(max(lo, t - w), min(hi, t + w + 1)))
+                idx += [idx[-1]] * (2 * w + 1 - len(idx))
+                out = sr.forward_cached(video[:, idx], feats[idx])
+                strength = self.enhancement_strength.item()
+                if strength < 1.0:
+                    out = _BlendFn.apply(out, video[:, lo:hi].detach().to(torch.float32).contiguous(), t - lo,
+                                         self.config.scale_factor, float(strength))
+                frames_out.append(out)
+                continue
             mask = corruption_masks[t:t + 1] if corruption_masks is not None else None
             frames_out.append(self.forward(video[:, lo:hi], center_idx=t - lo, corruption_mask=mask)["enhanced"])
         out = torch.stack(frames_out, dim=1)

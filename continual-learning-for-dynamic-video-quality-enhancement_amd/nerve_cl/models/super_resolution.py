@@ -187,6 +187,34 @@ class SuperResolutionNet(nn.Module):
             return out, inter
         return out
 
+    # ------------------------------------------------------------------ inference with cached per-frame features
+    def _act_dtype(self):
+        return torch.bfloat16 if (self.bf16_activations and self.math_mode == _nvq.MATH_BF16) else torch.float32
+
+    @torch.no_grad()
+    def extract_features(self, frames: torch.Tensor) -> torch.Tensor:
+        """Eval-mode FeatureExtractor output of every frame of a video, (B,Tv,C,H,W) -> opaque [Tv,B,H,W,F] tensor for
+        `forward_cached`.  In eval mode a frame's features do not depend on the window it is used in, so a sliding-window
+        caller (EnhancementEngine.enhance_video) needs them once per frame instead of once per window."""
+        if self.training:
+            raise RuntimeError("extract_features is an eval-mode (running BatchNorm statistics) inference path")
+        _nvq.require_device(frames, "frames")
+        return _engine.extract_features(self._tensor_dict(), frames.detach().to(torch.float32).contiguous(), self._F,
+                                        self.math_mode, self._act_dtype())
+
+    @torch.no_grad()
+    def forward_cached(self, lr_frames: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
+        """forward(lr_frames) with the frames' features (extract_features(...)[window indices]) supplied by the caller."""
+        if self.training:
+            raise RuntimeError("forward_cached is an eval-mode inference path")
+        B, T, C, H, W = lr_frames.shape
+        if T != self.num_frames:
+            raise RuntimeError(f"expected {self.num_frames} frames, got {T}")
+        out, _ = _engine.forward(self._tensor_dict(), lr_frames.detach().to(torch.float32).contiguous(), self._F, self._NB,
+                                 self.scale_factor, False, self.math_mode, self._act_dtype(),
+                                 features=features.contiguous())
+        return out
+
     def forward_single(self, lr_frame: torch.Tensor) -> torch.Tensor:
         """Upscale one frame: it is repeated T times (reference :393-405)."""
         return self.forward(lr_frame.unsqueeze(1).expand(-1, self.num_frames, -1, -1, -1))

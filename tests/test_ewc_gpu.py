@@ -148,3 +148,31 @@ def test_engine_strength_blend_and_enhance_video():
     with torch.no_grad():
         vid = eng.enhance_video(torch.rand(5, 3, 16, 16, device="cuda"))
     assert vid.shape == (5, 3, 32, 32)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_enhance_video_feature_cache_matches_uncached(bf16):
+    """enhance_video(cache_features=True) extracts every frame's features once for the whole clip (11 frames > NVQ_MAX_T, so
+    in two launches) and must give the results of the per-window path, clip boundaries and strength blend included."""
+    from nerve_cl import _nvq
+    from nerve_cl.models import EnhancementConfig, EnhancementEngine
+    torch.manual_seed(1)
+    eng = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True,
+                                              sr_num_features=64 if bf16 else 16, sr_num_residual_blocks=1)).cuda().eval()
+    if bf16:
+        eng.super_resolution.math_mode, eng.super_resolution.bf16_activations = _nvq.MATH_BF16, True
+    # non-trivial running statistics
+    for n, b in eng.super_resolution.named_buffers():
+        if n.endswith("running_mean"):
+            b.copy_(torch.randn_like(b) * 0.1)
+        elif n.endswith("running_var"):
+            b.copy_(torch.rand_like(b) + 0.5)
+    vid = torch.rand(11, 3, 24, 40, device="cuda")
+    with torch.no_grad():
+        a = eng.enhance_video(vid, cache_features=False)
+        b = eng.enhance_video(vid, cache_features=True)
+        eng.enhancement_strength.fill_(0.6)
+        c = eng.enhance_video(vid.unsqueeze(0).repeat(2, 1, 1, 1, 1), cache_features=False)
+        d = eng.enhance_video(vid.unsqueeze(0).repeat(2, 1, 1, 1, 1), cache_features=True)
+    assert a.shape == (11, 3, 48, 80) and torch.equal(a, b)
+    assert c.shape == (2, 11, 3, 48, 80) and torch.equal(c, d)
