@@ -92,11 +92,15 @@ class _SRFunction(torch.autograd.Function):
     def backward(ctx, dout):
         net, sv = ctx.net, ctx.sv
         if sv is None:
-            raise RuntimeError("SuperResolutionNet backward called without saved forward state")
+            raise RuntimeError("SuperResolutionNet backward called without saved forward state (a second backward through "
+                               "the same forward needs net.retain_backward_state = True, the analogue of retain_graph)")
         names = net._param_names
         flat, views = net._new_grad_bucket()
         _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
-        ctx.sv = None
+        # A custom Function cannot see retain_graph, and the state of a 540p step is tens of GB that must not outlive the
+        # backward (autograd frees its own saved tensors here too), so it is dropped unless the module asks to keep it.
+        if not getattr(net, "retain_backward_state", False):
+            ctx.sv = None
         hook = net._grad_bucket_hook
         if hook is not None:
             hook(flat)           # data-parallel all-reduce of the whole bucket (nerve_cl.parallel)
@@ -250,7 +254,8 @@ class _LightFunction(torch.autograd.Function):
             raise RuntimeError("LightweightSuperResolution backward called without saved forward state")
         flat, views = SuperResolutionNet._new_grad_bucket(net)
         _engine.light_backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
-        ctx.sv = None
+        if not getattr(net, "retain_backward_state", False):
+            ctx.sv = None
         if net._grad_bucket_hook is not None:
             net._grad_bucket_hook(flat)
         net._last_grad_bucket = flat
