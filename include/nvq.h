@@ -100,7 +100,8 @@ int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
  * buffer is read once instead of twice.  NVQ_MATH_BF16 only. */
 int nvq_rdb_tail_forward(const nvq_conv_desc* d3, const nvq_conv_desc* dl, void* stream);
 /* Diagnostics only (tools/kernel_phases.py): 0 = normal; 1 = bf16 conv kernels skip the MFMA section;
- * 2 = they skip the per-chunk global loads after the first chunk.  Results are wrong for mode != 0. */
+ * 2 = they skip the per-chunk global loads after the first chunk (results are wrong in modes 1 and 2);
+ * +4 = the cout <= 32 3x3 kernel uses its 8x32-pixel tiles instead of 16x32 (results unchanged). */
 int nvq_debug_set_conv_mode(int mode);
 size_t nvq_sizeof_conv_desc(void);
 
