@@ -497,16 +497,16 @@ __device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
     return dw_unpack4(*reinterpret_cast<const dw_u32x2*>(xs + hp * DB_C + 4 * c4));
 }
 
-// grid (tiles, C/64)
-__global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
+// grid (<= DB_MAXWG persistent workgroups over the tiles, C/64): the next tile's halo is fetched into registers while the
+// current tile is computed from LDS, so a workgroup always has loads in flight (the one-tile-per-workgroup form spent the
+// whole memory latency of every tile in its staging phase, with only the CU's second workgroup to cover it).
+constexpr int DB_MAXWG = 512;
+__global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
-                                                           int tilesY, int flip, int out_bf16, DwBn bn, DwEpi ep) {
+                                                           int tilesY, int ntiles, int flip, int out_bf16, DwBn bn, DwEpi ep) {
     __shared__ __attribute__((aligned(16))) __bf16 xs[DT_NPIX * DB_C];
-    int bt = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = bt % tilesX; bt /= tilesX;
-    const int ty = bt % tilesY;
-    const int n = bt / tilesY;
+    constexpr int PER = (DT_NPIX * 8 + DB_T - 1) / DB_T;
     const int ch0 = blockIdx.y * DB_C;
     const int c4 = threadIdx.x & 15, x = threadIdx.x >> 4;
     float4 w[9];
@@ -516,44 +516,108 @@ __global__ __launch_bounds__(DB_T) void dwconv_bf16_kernel(const __bf16* __restr
         const int c = ch0 + 4 * c4;
         w[t] = make_float4(weight[(c + 0) * 9 + tt], weight[(c + 1) * 9 + tt], weight[(c + 2) * 9 + tt], weight[(c + 3) * 9 + tt]);
     }
-    dw_stage_halo_bf16(in, in_ld, n, H, W, ty * DT_H, tx * DT_W, ch0, xs, bn);
-    __syncthreads();
-    const int gx = tx * DT_W + x;
-    float4 r[3][3];
+    dw_u32x4 v[PER];
+    unsigned okm = 0;
+    auto fetch = [&](int tile) {                              // raw loads (clamped addresses); masked at commit
+        int bt = xcd_tile(tile, ntiles);
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
+        okm = 0;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int k = 0; k < PER; ++k) {
+            const int item = threadIdx.x + k * DB_T;
+            const int hp = item >> 3, q = item & 7;
+            const int hy = hp / DT_HW, hx = hp - hy * DT_HW;
+            const int gy = ty * DT_H + hy - 1, gx = tx * DT_W + hx - 1;
+            const bool ok = item < DT_NPIX * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            okm |= (ok ? 1u : 0u) << k;
+            v[k] = *reinterpret_cast<const dw_u32x4*>(in + (ok ? ((size_t)(n * H + gy) * W + gx) * in_ld + ch0 + 8 * q : 0));
+        }
+    };
+    auto commit = [&](int n) {                                // (optional relu(bn(.))) -> LDS; zero padding stays zero
+        if (bn.mean) {                                        // uniform
+            const int c0 = ch0 + 8 * (threadIdx.x & 7);       // this thread's channel group (DB_T % 8 == 0)
+            const int g = n / bn.group_images;
+            float m[8], is[8], ga[8], be[8];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) r[a][b] = dw_lds4(xs, a * DT_HW + x + b, c4);
-#pragma unroll
-    for (int y = 0; y < DT_H; ++y) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) r[2][b] = dw_lds4(xs, (y + 2) * DT_HW + x + b, c4);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float4 v = r[a][b], ww = w[a * 3 + b];
-                acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
+            for (int e = 0; e < 8; ++e) {
+                m[e] = bn.mean[g * bn.C + c0 + e]; is[e] = bn.invstd[g * bn.C + c0 + e];
+                ga[e] = bn.gamma[c0 + e]; be[e] = bn.beta[c0 + e];
             }
-        const int gy = ty * DT_H + y;
-        if (gy < H && gx < W) {
-            const size_t pix = (size_t)(n * H + gy) * W + gx;
-            if (ep.add) {
-                const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
-                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                dw_u32x4 o;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    const float a = __uint_as_float(v[k][w2] << 16), b = __uint_as_float(v[k][w2] & 0xffff0000u);
+                    const float ya = fmaxf((a - m[2 * w2]) * is[2 * w2] * ga[2 * w2] + be[2 * w2], 0.f);
+                    const float yb = fmaxf((b - m[2 * w2 + 1]) * is[2 * w2 + 1] * ga[2 * w2 + 1] + be[2 * w2 + 1], 0.f);
+                    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                    const b2 pk = {(__bf16)ya, (__bf16)yb};
+                    o[w2] = __builtin_bit_cast(unsigned, pk);
+                }
+                v[k] = o;
             }
-            if (ep.mask) {
-                const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
-                if (!(m.x > 0.f)) acc.x = 0.f;
-                if (!(m.y > 0.f)) acc.y = 0.f;
-                if (!(m.z > 0.f)) acc.z = 0.f;
-                if (!(m.w > 0.f)) acc.w = 0.f;
-            }
-            stx4(out, pix * out_ld + ch0 + 4 * c4, out_bf16, acc);
         }
 #pragma unroll
-        for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+        for (int k = 0; k < PER; ++k) {
+            const int item = threadIdx.x + k * DB_T;
+            dw_u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (okm >> k) & 1 ? v[k][e] : 0u;
+            if (item < DT_NPIX * 8) *reinterpret_cast<dw_u32x4*>(xs + (item >> 3) * DB_C + 8 * (item & 7)) = o;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        int bt = xcd_tile(tile, ntiles);
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
+        commit(n);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        const int gx = tx * DT_W + x;
+        float4 r[3][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[a][b] = dw_lds4(xs, a * DT_HW + x + b, c4);
+#pragma unroll
+        for (int y = 0; y < DT_H; ++y) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r[2][b] = dw_lds4(xs, (y + 2) * DT_HW + x + b, c4);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float4 vv = r[a][b], ww = w[a * 3 + b];
+                    acc.x += vv.x * ww.x; acc.y += vv.y * ww.y; acc.z += vv.z * ww.z; acc.w += vv.w * ww.w;
+                }
+            const int gy = ty * DT_H + y;
+            if (gy < H && gx < W) {
+                const size_t pix = (size_t)(n * H + gy) * W + gx;
+                if (ep.add) {
+                    const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
+                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                }
+                if (ep.mask) {
+                    const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
+                    if (!(m.x > 0.f)) acc.x = 0.f;
+                    if (!(m.y > 0.f)) acc.y = 0.f;
+                    if (!(m.z > 0.f)) acc.z = 0.f;
+                    if (!(m.w > 0.f)) acc.w = 0.f;
+                }
+                stx4(out, pix * out_ld + ch0 + 4 * c4, out_bf16, acc);
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+        }
+        __syncthreads();                                      // everyone is done with xs before the next commit
     }
 }
 
@@ -964,9 +1028,12 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
     if (C % DB_C == 0 && in_bf16) {
         NVQ_REQUIRE(in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv_forward(bf16): ld %d/%d must be multiples of 8", in_ld, out_ld);
         const int tilesX = (W + DT_W - 1) / DT_W, tilesY = (H + DT_H - 1) / DT_H;
-        hipLaunchKernelGGL(dwconv_bf16_kernel, dim3((unsigned)((long)tilesX * tilesY * N), C / DB_C), dim3(DB_T), 0,
+        const int ntiles = tilesX * tilesY * N;
+        int nwg = ntiles < DB_MAXWG ? ntiles : DB_MAXWG;
+        if (nwg >= 8) nwg &= ~7;                              // multiple of the XCD count, see xcd_tile()
+        hipLaunchKernelGGL(dwconv_bf16_kernel, dim3(nwg, C / DB_C), dim3(DB_T), 0,
                            (hipStream_t)stream, reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W,
-                           tilesX, tilesY, flip, out_bf16, make_dwbn(bn, C), ep);
+                           tilesX, tilesY, ntiles, flip, out_bf16, make_dwbn(bn, C), ep);
         return check_launch("dwconv_bf16");
     }
     if (C % DT_C == 0) {
