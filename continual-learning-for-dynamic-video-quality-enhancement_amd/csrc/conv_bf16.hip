@@ -252,6 +252,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
         }
     }
+    if constexpr (NB == 2 && KS == 3) {
+        // cout <= 32: stage the tile's output in LDS and store whole 64-byte pixel rows
+        const bool staged = d.out_bf16 && vec_ok && !d.out2 && !d.res && !d.accumulate && d.cout_store == NT && cz == 0;
+        if (staged) {                                        // workgroup-uniform
+            static_assert(2 * TW * STAGE_PX * NW <= NPIX * XSB, "staging tiles fit the activation stage");
+            __syncthreads();                                 // every wave is done reading xs
+            __bf16* stage = xs + wave * (2 * TW * STAGE_PX);
+            conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int item = lane + k * 64;
+                const int px = item >> 2, piece = item & 3;  // wave-local pixel (2 rows x 32), 8-channel piece
+                const int gy = ty * TH_ + 2 * wave + (px >> 5), gx = tx * TW + (px & 31);
+                if (gy < H && gx < W)
+                    *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d.out_ld + d.out_coff + 8 * piece) =
+                        *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX + 8 * piece);
+            }
+            return;
+        }
+    }
     conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_);
 }
 
