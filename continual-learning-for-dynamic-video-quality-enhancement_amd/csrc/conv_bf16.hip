@@ -430,22 +430,9 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
     __syncthreads();                                          // every wave is done with xs / ws / wl
     reinterpret_cast<u32x4*>(wl)[tid] = lr;                   // lff weights of channels [cin, cin + 32)
     __bf16* t4 = ws;                                          // [8 x 32 px][T4S]
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-        const int px = (2 * wave + (pb >> 1)) * TW + (pb & 1) * 16 + c;
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            const int co = cb * 16 + 4 * g;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[cb][pb][e] + (d3.bias ? d3.bias[co + e] : 0.f);
-                if (d3.relu) v[e] = fmaxf(v[e], 0.f);
-                v[e] *= d3.alpha;
-            }
-            *reinterpret_cast<bf16x4*>(t4 + px * T4S + co) = cvt4(make_float4(v[0], v[1], v[2], v[3]));
-        }
-    }
+    static_assert(T4S == STAGE_PX, "the y4 tile is the epilogue's staging tile");
+    // the regular epilogue (bias, ReLU, bit masks) with the wave's rows of t4 as its staging tile
+    conv_epilogue<NB>(d3, acc, n, ty, tx, 0, wave, c, g, vec3, TH, t4 + wave * (2 * TW * T4S));
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < NBL; ++cb) {
@@ -457,7 +444,19 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
             lacc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf, lacc[cb][pb], 0, 0, 0);
         }
     }
-    conv_epilogue<NB>(d3, acc, n, ty, tx, 0, wave, c, g, vec3);
+    {   // y4 to the concat buffer as whole 64-byte pixel rows
+        __bf16* o16 = reinterpret_cast<__bf16*>(d3.out);
+        const __bf16* stage = t4 + wave * (2 * TW * T4S);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = lane + k * 64;
+            const int px = item >> 2, piece = item & 3;
+            const int gy = ty * TH + 2 * wave + (px >> 5), gx = tx * TW + (px & 31);
+            if (gy < H && gx < W)
+                *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d3.out_ld + d3.out_coff + 8 * piece) =
+                    *reinterpret_cast<const u32x4*>(stage + px * T4S + 8 * piece);
+        }
+    }
     conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
 }
 
