@@ -252,25 +252,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
         }
     }
-    if constexpr (NB == 2 && KS == 3) {
-        // cout <= 32: stage the tile's output in LDS and store whole 64-byte pixel rows
-        const bool staged = d.out_bf16 && vec_ok && !d.out2 && !d.res && !d.accumulate && d.cout_store == NT && cz == 0;
+    constexpr int SPX = NB == 2 ? STAGE_PX : STAGE_PX64;
+    if constexpr (NB >= 2 && 2 * TW * SPX * NW <= NPIX * XSB + WS_HALFS) {
+        // full 32 / 64-channel bf16 outputs: stage the tile's output in LDS and store whole pixel rows (64 / 128 B)
+        constexpr int PPP = NT / 8;                          // 16-byte pieces per pixel
+        const bool staged = d.out_bf16 && vec_ok && d.cout_store - cz * NT >= NT;
         if (staged) {                                        // workgroup-uniform
-            static_assert(2 * TW * STAGE_PX * NW <= NPIX * XSB, "staging tiles fit the activation stage");
-            __syncthreads();                                 // every wave is done reading xs
-            __bf16* stage = xs + wave * (2 * TW * STAGE_PX);
-            conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage);
+            __syncthreads();                                 // every wave is done reading xs / ws
+            __bf16* stage = lds + wave * (2 * TW * SPX);
+            conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage, SPX);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PPP; ++k) {
                 const int item = lane + k * 64;
-                const int px = item >> 2, piece = item & 3;  // wave-local pixel (2 rows x 32), 8-channel piece
+                const int px = item / PPP, piece = item % PPP;  // wave-local pixel (2 rows x 32), 8-channel piece
                 const int gy = ty * TH_ + 2 * wave + (px >> 5), gx = tx * TW + (px & 31);
                 if (gy < H && gx < W)
-                    *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d.out_ld + d.out_coff + 8 * piece) =
-                        *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX + 8 * piece);
+                    *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d.out_ld + d.out_coff + cz * NT + 8 * piece) =
+                        *reinterpret_cast<const u32x4*>(stage + px * SPX + 8 * piece);
             }
             return;
         }
@@ -456,6 +457,25 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
                 *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d3.out_ld + d3.out_coff + 8 * piece) =
                     *reinterpret_cast<const u32x4*>(stage + px * T4S + 8 * piece);
         }
+    }
+    if (dl.out_bf16) {                                        // lff output as whole 128-byte pixel rows (uniform)
+        static_assert(2 * TW * STAGE_PX64 * 4 <= NPIX * XSB + WS3, "lff staging tiles fit the LDS stages");
+        __syncthreads();                                      // every wave is done with t4 / wl
+        __bf16* stage = lds + wave * (2 * TW * STAGE_PX64);
+        conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl, TH, stage, STAGE_PX64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __bf16* o16 = reinterpret_cast<__bf16*>(dl.out);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int item = lane + k * 64;
+            const int px = item >> 3, piece = item & 7;
+            const int gy = ty * TH + 2 * wave + (px >> 5), gx = tx * TW + (px & 31);
+            if (gy < H && gx < W)
+                *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * dl.out_ld + dl.out_coff + 8 * piece) =
+                    *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX64 + 8 * piece);
+        }
+        return;
     }
     conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
 }

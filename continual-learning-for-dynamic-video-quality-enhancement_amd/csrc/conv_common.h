@@ -44,14 +44,15 @@ __device__ __forceinline__ void wgrad_bias_partial(const nvq_wgrad_desc& d, floa
 // Epilogue of the forward / input-gradient kernels.  acc[cb][pb] is the 16x16 MFMA result with
 // M = output channel, N = pixel: lane (c = lane & 15, g = lane >> 4) holds channels
 // cz*NB*16 + cb*16 + 4g .. +3 of pixel (row = 2*wave + (pb >> 1), x = (pb & 1)*16 + c) of the tile.
-// stage != nullptr (bf16 output, vector path, no out2 / res / accumulate): the value is written as bf16 to the wave's LDS
-// staging tile [2 rows x 32 px][STAGE_PX halfs] instead of global memory; the caller then stores it as whole 64-byte pixel
-// rows (16 B per lane).  A lane's 8-byte pieces of 16 pixels at the tensor's pixel stride are the expensive way to write.
-constexpr int STAGE_PX = 40;   // halfs per staged pixel (80 B: 16-byte aligned rows)
+// stage != nullptr (bf16 output, vector path): the final value is written as bf16 to the wave's LDS staging tile
+// [2 rows x 32 px][stage_px halfs] instead of global memory; the caller then stores it as whole pixel rows (16 B per lane).
+// A lane's 8-byte pieces of 16 pixels at the tensor's pixel stride are the expensive way to write.
+constexpr int STAGE_PX = 40;   // halfs per staged pixel for 32 output channels (80 B: 16-byte aligned rows)
+constexpr int STAGE_PX64 = 72; // ... for 64 output channels (144 B)
 template <int NB>
 __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&acc)[NB][4], int n, int ty, int tx,
                                               int cz, int wave, int c, int g, int vec_ok, int th = TH,
-                                              __bf16* stage = nullptr) {
+                                              __bf16* stage = nullptr, int stage_px = STAGE_PX) {
     constexpr int NT = NB * 16;
     const int H = d.h, W = d.w;
 #pragma unroll
@@ -110,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                     }
                 }
                 if (stage)
-                    *reinterpret_cast<bf16x4*>(stage + ((pb >> 1) * TW + (pb & 1) * 16 + c) * STAGE_PX + co) =
+                    *reinterpret_cast<bf16x4*>(stage + ((pb >> 1) * TW + (pb & 1) * 16 + c) * stage_px + co - cz * NT) =
                         (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 else
                     stx4(d.out, oi, d.out_bf16, make_float4(v[0], v[1], v[2], v[3]));
