@@ -220,3 +220,56 @@ class OnlineEWC(EWC):
 
     def __init__(self, model: nn.Module, ewc_lambda: float = 5000.0, decay: float = 0.999):
         super().__init__(model, ewc_lambda, mode="online", decay=decay)
+
+
+
+class SynapticIntelligence:
+    """Synaptic Intelligence (Zenke et al. 2017) with the reference's interface (nerve_cl/continual/ewc.py:306-379):
+    ``update_importance()`` after every optimizer step (W += -grad * (theta - theta_prev)), ``register_task()`` at a task
+    end (omega += W / (delta^2 + damping)), ``penalty()`` = si_lambda * sum omega (theta - theta_old)^2.
+
+    W, theta_old and omega live in one flat fp32 bucket each (``W`` / ``p_old`` / ``omega`` are dicts of views into them,
+    keyed by parameter name as in the reference); the penalty and its gradient are the same two libnvq kernels EWC uses
+    (``nvq_ewc_penalty`` with lambda = 2 * si_lambda, Fisher := omega, theta* := theta_old)."""
+
+    def __init__(self, model: nn.Module, si_lambda: float = 1.0, damping: float = 0.1):
+        self.model = model
+        self.si_lambda = si_lambda
+        self.damping = damping
+        self._named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError(f"SynapticIntelligence needs the model on the GPU (found {dev}); there is no CPU fallback")
+        n = sum(p.numel() for _, p in self._named)
+        self._W = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._omega = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._p_old = self._theta()
+        self.W = _flat_views(self._W, self._named)
+        self.omega = _flat_views(self._omega, self._named)
+        self.p_old = _flat_views(self._p_old, self._named)
+
+    def _theta(self) -> torch.Tensor:
+        return torch.cat([p.detach().reshape(-1).float() for _, p in self._named])
+
+    def _set_p_old(self, theta: torch.Tensor) -> None:
+        self._p_old.copy_(theta)                              # the views in self.p_old stay valid
+
+    def update_importance(self) -> None:
+        """Call after each optimizer step (parameters without a gradient contribute nothing, as in the reference)."""
+        theta = self._theta()
+        g = torch.cat([(p.grad.detach().reshape(-1).float() if p.grad is not None else torch.zeros(p.numel(), device=theta.device))
+                       for _, p in self._named])
+        has = torch.cat([torch.full((p.numel(),), p.grad is not None, dtype=torch.bool, device=theta.device)
+                         for _, p in self._named])
+        self._W.add_(torch.where(has, -g * (theta - self._p_old), torch.zeros_like(g)))
+        self._set_p_old(torch.where(has, theta, self._p_old))
+
+    def register_task(self) -> None:
+        theta = self._theta()
+        delta = theta - self._p_old
+        self._omega.add_(self._W / (delta * delta + self.damping))
+        self._W.zero_()
+        self._set_p_old(theta)
+
+    def penalty(self) -> torch.Tensor:
+        return _PenaltyFn.apply(2.0 * self.si_lambda, self._p_old, self._omega, *[p for _, p in self._named])

@@ -95,3 +95,41 @@ class EpisodicMemory:
     def load(self, path: str) -> None:
         blob = torch.load(path, weights_only=False)   # a file this class wrote itself
         self.capacity, self.strategy, self._seen, self._items = blob["capacity"], blob["strategy"], blob["seen"], blob["items"]
+
+
+
+class StreamingEpisodicMemory(EpisodicMemory):
+    """Reservoir memory with a recency-biased sampler (reference memory.py:352-440): sampling weight of an item =
+    (1 - recency_weight) * importance + recency_weight / (1 + now - time stored)."""
+
+    def __init__(self, capacity: int = 1000, recency_weight: float = 0.2, compress_old: bool = True, seed: Optional[int] = None):
+        super().__init__(capacity, strategy="reservoir", seed=seed)
+        self.recency_weight, self.compress_old = recency_weight, compress_old
+        self.current_time = 0
+
+    def store(self, lr: torch.Tensor, hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
+              importance: float = 1.0) -> bool:
+        self.current_time += 1
+        meta = dict(metadata or {})
+        meta["_time"] = self.current_time
+        return super().store(lr, hr, meta, importance)
+
+    def sample(self, batch_size: int = 32, content_type: Optional[str] = None, device: Optional[torch.device] = None,
+               use_recency: bool = True):
+        if not use_recency:
+            return super().sample(batch_size, device=device, content_type=content_type)
+        if not self._items:
+            raise ValueError("memory is empty")
+        batch_size = min(batch_size, len(self._items))
+        w = [(1 - self.recency_weight) * it["importance"] + self.recency_weight / (1 + self.current_time - it["meta"]["_time"])
+             for it in self._items]
+        idx: List[int] = []
+        pool = list(range(len(self._items)))
+        for _ in range(batch_size):                           # weighted sampling without replacement
+            j = self._rng.choices(range(len(pool)), weights=[w[i] for i in pool])[0]
+            idx.append(pool.pop(j))
+        lr = torch.stack([self._items[i]["lr"] for i in idx])
+        hr = torch.stack([self._items[i]["hr"] for i in idx])
+        if device is not None:
+            lr, hr = lr.to(device), hr.to(device)
+        return lr, hr, [{k: v for k, v in self._items[i]["meta"].items() if k != "_time"} for i in idx]

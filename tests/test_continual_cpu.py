@@ -1,5 +1,6 @@
 """CPU: host-side continual-learning helpers (replay memory, FOMAML, distillation) stay importable and
 behave as the reference's own tests expect (tests/test_continual.py:14-55,92-123)."""
+import pytest
 import torch
 import torch.nn as nn
 
@@ -44,3 +45,40 @@ def test_fomaml_adapt_and_distillation_on_plain_modules():
 def test_ewc_constructs_on_cpu_but_refuses_to_compute_there():
     ewc = EWC(nn.Linear(4, 4), ewc_lambda=10)
     assert ewc.penalty() == 0.0 and ewc.num_tasks == 0 and ewc.mode == "online" and ewc.decay == 0.999
+
+
+def test_maml_train_step_reptile_and_streaming_memory_on_plain_modules():
+    """Reference package surface (nerve_cl/continual/__init__.py): MAML / Reptile / ContentAdaptiveMAML /
+    StreamingEpisodicMemory run on any nn.Module (these helpers are host-side loops)."""
+    from nerve_cl.continual import MAML, Reptile, ContentAdaptiveMAML, StreamingEpisodicMemory
+    torch.manual_seed(0)
+    loss = nn.MSELoss()
+
+    def make_tasks():
+        return [{"support": (torch.randn(8, 6), torch.randn(8, 3)), "query": (torch.randn(8, 6), torch.randn(8, 3))}
+                for _ in range(3)]
+    model = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 3))
+    maml = MAML(model, inner_lr=0.05, outer_lr=1e-2, inner_steps=2)
+    before = [p.detach().clone() for p in model.parameters()]
+    v = maml.train_step(make_tasks(), loss)
+    assert isinstance(v, float) and any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    state = maml.state_dict()
+    assert set(state) == {"model", "meta_optimizer", "inner_lr", "outer_lr", "inner_steps", "first_order"}
+    maml.load_state_dict(state)
+    with pytest.raises(NotImplementedError):
+        MAML(model, first_order=False).meta_step(make_tasks(), loss)
+    # Reptile: theta <- theta + outer_lr * (mean adapted - theta); with outer_lr = 0 nothing moves
+    rep = Reptile(model, inner_lr=0.05, outer_lr=0.0, inner_steps=2)
+    before = [p.detach().clone() for p in model.parameters()]
+    rep.train_step(make_tasks(), loss)
+    assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    Reptile(model, outer_lr=0.5, inner_steps=2).train_step(make_tasks(), loss)
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    cam = ContentAdaptiveMAML(model, ["sports", "animation"], inner_lr=0.02)
+    assert isinstance(cam.adapt_to_content(make_tasks()[0]["support"], "sports", loss, steps=1), nn.Module)
+    mem = StreamingEpisodicMemory(capacity=16, recency_weight=0.9, seed=1)
+    for i in range(40):
+        mem.store(torch.full((3, 4, 4), float(i)), torch.full((3, 8, 8), float(i)), {"content_type": "a", "i": i})
+    lr, hr, meta = mem.sample(8)
+    assert lr.shape == (8, 3, 4, 4) and hr.shape == (8, 3, 8, 8) and len({m["i"] for m in meta}) == 8
+    assert all("_time" not in m for m in meta)

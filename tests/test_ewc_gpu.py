@@ -176,3 +176,45 @@ def test_enhance_video_feature_cache_matches_uncached(bf16):
         d = eng.enhance_video(vid.unsqueeze(0).repeat(2, 1, 1, 1, 1), cache_features=True)
     assert a.shape == (11, 3, 48, 80) and torch.equal(a, b)
     assert c.shape == (2, 11, 3, 48, 80) and torch.equal(c, d)
+
+
+def test_synaptic_intelligence_matches_reference_formulas():
+    """SynapticIntelligence (reference ewc.py:306-379) on flat buckets + the HIP penalty kernels against a direct
+    per-tensor evaluation of the reference's formulas on the same parameter / gradient sequence."""
+    from nerve_cl.continual import SynapticIntelligence
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
+    si = SynapticIntelligence(model, si_lambda=0.7, damping=0.1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    # reference bookkeeping, per tensor
+    W = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    p_old = {n: p.detach().clone() for n, p in model.named_parameters()}
+    omega = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    x, y = torch.randn(16, 7, device="cuda"), torch.randn(16, 3, device="cuda")
+    for task in range(2):
+        for _ in range(3):
+            opt.zero_grad()
+            (torch.nn.functional.mse_loss(model(x), y) + si.penalty()).backward()
+            opt.step()
+            si.update_importance()
+            for n, p in model.named_parameters():
+                W[n] += -p.grad * (p.detach() - p_old[n])
+                p_old[n] = p.detach().clone()
+        si.register_task()
+        for n, p in model.named_parameters():
+            delta = p.detach() - p_old[n]
+            omega[n] += W[n] / (delta ** 2 + 0.1)
+            W[n] = torch.zeros_like(p)
+            p_old[n] = p.detach().clone()
+        with torch.no_grad():                      # move the weights so that the penalty is non-zero
+            for p in model.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        want = 0.7 * sum((omega[n] * (p - p_old[n]) ** 2).sum() for n, p in model.named_parameters())
+        got = si.penalty()
+        assert abs(got.item() - want.item()) <= 1e-5 * max(1.0, abs(want.item()))
+        model.zero_grad()
+        got.backward()
+        for n, p in model.named_parameters():
+            ref = 2 * 0.7 * omega[n] * (p.detach() - p_old[n])
+            assert (p.grad - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), n
+            assert torch.allclose(si.omega[n], omega[n], rtol=1e-5, atol=1e-7)
