@@ -169,3 +169,32 @@ class EnhancementEngine(nn.Module):
         elif mode == "lightweight":
             self.config.frame_recovery_enabled, self.config.super_resolution_enabled = False, True
             self.config.use_lightweight_sr = True
+
+
+
+class AdaptiveEnhancementEngine(EnhancementEngine):
+    """Enhancement strength / mode chosen from a content-complexity estimate, a resource budget and a user preference
+    (reference enhancement_engine.py:295-381).  The estimator is a 3x8x8 -> 64 -> 1 MLP on the pooled centre frame - a few
+    hundred FLOPs, left to stock PyTorch ops; the enhancement itself is the HIP path of EnhancementEngine."""
+
+    def __init__(self, config: Optional[EnhancementConfig] = None):
+        super().__init__(config)
+        self.complexity_estimator = nn.Sequential(nn.AdaptiveAvgPool2d(8), nn.Flatten(), nn.Linear(3 * 8 * 8, 64),
+                                                  nn.ReLU(inplace=True), nn.Linear(64, 1), nn.Sigmoid())
+
+    def estimate_complexity(self, frame: torch.Tensor) -> torch.Tensor:
+        """(B,C,H,W) -> (B,1) in [0,1]."""
+        return self.complexity_estimator(frame)
+
+    def adaptive_forward(self, frames: torch.Tensor, resource_budget: float = 1.0,
+                         user_quality_preference: float = 0.5) -> Dict[str, torch.Tensor]:
+        B, T, C, H, W = frames.shape
+        complexity = self.estimate_complexity(frames[:, T // 2])
+        strength = 0.3 * resource_budget + 0.3 * user_quality_preference + 0.4 * complexity.mean().item()
+        strength = min(1.0, max(0.3, strength))
+        # like the reference, the mode only flips config flags; the modules built in __init__ stay as they are
+        self.set_enhancement_mode("lightweight" if resource_budget < 0.3 else "sr_only" if resource_budget < 0.6 else "full")
+        results = self.forward(frames=frames, enhancement_strength=strength)
+        results["complexity"] = complexity
+        results["enhancement_strength"] = strength
+        return results

@@ -150,6 +150,32 @@ def test_engine_strength_blend_and_enhance_video():
     assert vid.shape == (5, 3, 32, 32)
 
 
+def test_adaptive_engine_strength_mode_and_names():
+    """AdaptiveEnhancementEngine.adaptive_forward (reference enhancement_engine.py:336-381): strength =
+    clamp(0.3*budget + 0.3*pref + 0.4*mean(complexity), 0.3, 1), mode from the budget, extra result keys."""
+    import nerve_cl
+    from nerve_cl.models import AdaptiveEnhancementEngine, EnhancementConfig, FrameRecoveryNet
+    assert {"FrameRecoveryNet", "SuperResolutionNet", "EnhancementEngine", "EpisodicMemory", "EWC", "MAML"} <= set(nerve_cl.__all__)
+    with pytest.raises(NotImplementedError, match="frame_recovery_enabled=False"):
+        FrameRecoveryNet()
+    torch.manual_seed(1)
+    eng = AdaptiveEnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, sr_num_features=16,
+                                                      sr_num_residual_blocks=1)).cuda().eval()
+    frames = torch.rand(2, 3, 3, 24, 24, device="cuda")
+    with torch.no_grad():
+        res = eng.adaptive_forward(frames, resource_budget=0.5, user_quality_preference=0.8)
+        cx = eng.estimate_complexity(frames[:, 1])
+        plain = eng(frames, enhancement_strength=res["enhancement_strength"])["enhanced"]
+    assert res["complexity"].shape == (2, 1) and torch.equal(res["complexity"], cx)
+    want = min(1.0, max(0.3, 0.3 * 0.5 + 0.3 * 0.8 + 0.4 * cx.mean().item()))
+    assert abs(res["enhancement_strength"] - want) < 1e-7 and want < 1.0
+    assert torch.equal(res["enhanced"], plain) and not torch.equal(res["enhanced"], res["super_resolved"])
+    assert (eng.config.frame_recovery_enabled, eng.config.super_resolution_enabled) == (False, True)   # 'sr_only'
+    with torch.no_grad():
+        eng.adaptive_forward(frames, resource_budget=0.1)
+    assert eng.config.use_lightweight_sr        # flag only; the modules are not rebuilt (as in the reference)
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_enhance_video_feature_cache_matches_uncached(bf16):
     """enhance_video(cache_features=True) extracts every frame's features once for the whole clip (11 frames > NVQ_MAX_T, so
