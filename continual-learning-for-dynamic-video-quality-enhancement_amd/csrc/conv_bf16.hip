@@ -91,9 +91,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;
     constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread of the first 4 waves (exact)
     constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
+    constexpr int CT_K = (TAPS / 2) * 4 * NT / 256;           // the centre tap's 4 * NT pieces: register index and
+    constexpr bool LIGHTW = true;
+    constexpr int CT_N = 4 * NT;                              // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
+    static_assert(((TAPS / 2) * 4 * NT) % 256 == 0 && CT_N <= 256, "the centre tap starts a 256-piece row");
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;
+    const int kcl = KS == 3 ? d.center_cin / KCB : 0;         // leading chunks that only have a centre tap
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,12 +163,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
-        if (NW == 4 || tid < 256) {                           // wave-uniform: the slab is 256 x WPER pieces
+        if (LIGHTW && kc < kcl) {                             // centre-tap-only chunk: one tap's 4 * NT pieces (wave-uniform)
+            if (tid < CT_N) wr[CT_K] = wsrc[tid + CT_K * 256];
+        } else if (NW == 4 || tid < 256) {                    // wave-uniform: the slab is 256 x WPER pieces
 #pragma unroll
             for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int kc) {
         const u32x4 z = {0u, 0u, 0u, 0u};
         if (interior) {                                      // workgroup-uniform
 #pragma unroll
@@ -189,29 +196,56 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
                 }
             }
         }
-        if (NW == 4 || tid < 256) {
+        if (LIGHTW && kc < kcl) {
+            if (tid < CT_N) reinterpret_cast<u32x4*>(ws)[tid + CT_K * 256] = wr[CT_K];
+        } else if (NW == 4 || tid < 256) {
 #pragma unroll
             for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
         }
     };
 
-    fetch(0);
-    for (int kc = 0; kc < nkc; ++kc) {
+    auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
+    };
+    auto ldW = [&](int tap, int cb) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+    };
+    auto stage_chunk = [&](int kc) {                          // chunk kc: registers -> LDS, chunk kc + 1: memory -> registers
         __syncthreads();
-        commit();
+        commit(kc);
         __syncthreads();
         if (kc + 1 < nkc && dbg != 2) fetch(kc + 1);
+    };
+
+    fetch(0);
+    int kc = 0;
+    // Leading chunks whose weights are zero outside the centre tap (nvq_conv_desc::center_cin): one stage instead of nine.
+    // A loop of its own - as a branch inside the main loop it cost the main path 60 VGPRs.
+    if constexpr (KS == 3) {
+        for (; kc < kcl; ++kc) {
+            stage_chunk(kc);
+            if (dbg == 1) continue;
+            bf16x8 p0[2], p1[2], wc[NB];
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) wc[cb] = ldW(TAPS / 2, cb);
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) { p0[xh] = ldP(1, xh, 1); p1[xh] = ldP(2, xh, 1); }
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p0[xh], acc[cb][xh], 0, 0, 0);
+                    acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p1[xh], acc[cb][2 + xh], 0, 0, 0);
+                }
+        }
+    }
+    for (; kc < nkc; ++kc) {
+        stage_chunk(kc);
         if (dbg == 1) continue;
         // Fragment reads software-pipelined against the MFMAs (the compiler otherwise emits read -> lgkmcnt(0) ->
         // 4 MFMAs, exposing the LDS latency 2*TAPS times per chunk).  Stages run dx-major, dy-minor: going from dy to
         // dy+1 the wave's upper output row reuses the fragments of the lower one, so a stage needs only the two
         // fragments of one new halo row; those, and the next stage's weights, are read one stage ahead.
-        auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
-            return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
-        };
-        auto ldW = [&](int tap, int cb) -> bf16x8 {
-            return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
-        };
         bf16x8 lo[2], hi[2], wa[NB], wn[NB];
         lo[0] = ldP(0, 0, 0); lo[1] = ldP(0, 1, 0);
 #pragma unroll

@@ -464,6 +464,8 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     NVQ_REQUIRE(d.out_coff + d.cout_store <= d.out_ld, "conv_forward: output slice exceeds ld");
     NVQ_REQUIRE(aligned16(d.wpack), "conv_forward: wpack alignment");
     NVQ_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0, "conv_forward: empty shape");
+    NVQ_REQUIRE(d.center_cin >= 0 && d.center_cin % 32 == 0 && d.center_cin <= d.cin && (d.center_cin == 0 || d.ksize == 3),
+                "conv_forward: center_cin %d (3x3 only, multiple of 32, <= cin %d)", d.center_cin, d.cin);
     const int NT = choose_nt(d.cout);
     const int ncz = (d.cout_store + NT - 1) / NT;
     NVQ_REQUIRE(ncz == (d.cout + NT - 1) / NT, "conv_forward: cout_store %d crosses a pack chunk", d.cout_store);

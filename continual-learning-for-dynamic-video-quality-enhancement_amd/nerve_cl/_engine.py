@@ -297,6 +297,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
 
     # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
     K.TIMER_TAG = "rdb"
+    # the gout channels of the mirror-form convs only carry the 1x1 lff^T term: the bf16 kernels skip their other taps
+    ctr = F if (math == K.MATH_BF16 and F % 32 == 0) else 0
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
@@ -309,15 +311,16 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             dy = Sl(dcat, GROWTH, cinb)                      # slot of dy_i
             if sv.bits is not None:
                 K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
-                               math=math, bits=sv.bits[k][i], bits_mode=2)
+                               math=math, bits=sv.bits[k][i], bits_mode=2, center_cin=ctr)
             else:
                 K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
-                               mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math)
+                               mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
             cin = F + GROWTH * i
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
         nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
-        K.conv_forward(Sl(dcat, g.CAT, 0), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math)
+        K.conv_forward(Sl(dcat, g.CAT, 0), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math,
+                       center_cin=ctr)
     K.TIMER_TAG = ""
     dprev = Sl(dagg)
 

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
         ("accumulate", ci),
         ("math", ci),
         ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
-        ("bits", vp), ("bits_mode", ci),
+        ("bits", vp), ("bits_mode", ci), ("center_cin", ci),
     ]
 
 
@@ -309,8 +309,9 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
-                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> ConvDesc:
-    """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask."""
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0) -> ConvDesc:
+    """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask.
+    center_cin: leading input channels whose weights are zero outside the centre tap (a hint, see nvq_conv_desc)."""
     n, h, w, _ = x.t.shape
     assert out.t.shape[:3] == x.t.shape[:3]
     d = ConvDesc()
@@ -334,6 +335,7 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
     if bits_mode:
         assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape) == (n, h, w) and bits.is_contiguous()
         d.bits, d.bits_mode = ptr(bits), bits_mode
+    d.center_cin = center_cin
     return d
 
 
@@ -342,12 +344,12 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
-                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0) -> None:
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0) -> None:
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
     d = _conv_desc(x, wpack, bias, out, ksize, relu=relu, alpha=alpha, accumulate=accumulate, cout_store=cout_store,
                    out2=out2, res=res, mask=mask, mask_c0=mask_c0, mask_c1=mask_c1, math=math, bits=bits,
-                   bits_mode=bits_mode)
+                   bits_mode=bits_mode, center_cin=center_cin)
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
     if ev0 is not None:
         cin = x.c if alg_cin is None else alg_cin
@@ -355,11 +357,12 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
         nbytes = cin * esz(x) + out.c * esz(out) * (2 if accumulate else 1) \
             + (res.c * esz(res) if res is not None else 0) + (out2.c * esz(out2) if out2 is not None else 0) \
             + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0) + (4 if bits_mode else 0)
-        TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * cin * out.c * ksize * ksize,
+        TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * (cin * ksize * ksize - center_cin * (ksize * ksize - 1)) * out.c,
                    n * h * w * nbytes, f"n{n} cin{x.c}{'h' if x.bf16 else ''} cout{out.c}{'h' if out.bf16 else ''}"
                    + (" acc" if accumulate else "")
                    + (" res" if res is not None else "") + (" mask" if mask is not None else "")
-                   + (" bitsW" if bits_mode == 1 else " bitsR" if bits_mode == 2 else ""))
+                   + (" bitsW" if bits_mode == 1 else " bitsR" if bits_mode == 2 else "")
+                   + (f" ctr{center_cin}" if center_cin else ""))
 
 
 def rdb_tail_forward(x: Sl, w3: torch.Tensor, b3, y4: Sl, wl: torch.Tensor, bl, out: Sl, *, alpha: float, res: Sl,

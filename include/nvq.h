@@ -89,6 +89,10 @@ typedef struct nvq_conv_desc {
      * conv: 4 bytes per pixel instead of 64); 0: unused. */
     unsigned* bits;
     int bits_mode;
+    /* 3x3 only, a hint: the packed weights of input channels [0, center_cin) are zero outside the centre tap (the
+     * 0.2*lff^T part of the mirror-form dense-block gradient convs, nvq_rdb_backward_weights), so the kernel may skip the
+     * other eight taps of those channels.  Multiple of 32, <= cin; 0 = no such channels.  Results do not depend on it. */
+    int center_cin;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */

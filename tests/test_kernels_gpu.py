@@ -698,6 +698,31 @@ def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
     assert rel(from_nhwc(out), refm) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,ctr,in16,H,W", [(96, 32, 64, True, 35, 41), (64, 32, 64, True, 20, 33), (224, 64, 64, True, 19, 40),
+                                                    (128, 32, 32, False, 12, 37), (96, 16, 64, True, 9, 30)])
+def test_conv_bf16_center_cin_hint(K, cin, cout, ctr, in16, H, W):
+    """nvq_conv_desc::center_cin: input channels [0, ctr) whose weights are zero outside the centre tap (the lff^T part of the
+    mirror-form dense-block gradient convs) skip the other eight taps: bit-identical to the same launch without the hint,
+    and equal to the reference conv; all tile shapes (cout 16 / 32 tall and short / 64, fp32 and bf16 inputs)."""
+    N = 2
+    w = rnd(cout, cin, 3, 3, scale=0.1)
+    centre = w[:, :ctr, 1, 1].clone()
+    w[:, :ctr] = 0
+    w[:, :ctr, 1, 1] = centre
+    x = bf(rnd(N, cin, H, W, seed=3))
+    xin = to_nhwc_bf16(x, 256) if in16 else to_nhwc(x)
+    wp = K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16)
+    outs = []
+    for hint in (0, ctr):
+        out = torch.full((N, H, W, cout), 7.0, device="cuda")
+        K.conv_forward(K.Sl(xin, cin, 0), wp, None, K.Sl(out), 3, math=K.MATH_BF16, center_cin=hint)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert rel(from_nhwc(outs[1]), F.conv2d(x, bf(w), None, padding=1)) < TOL
+    with pytest.raises(RuntimeError, match="center_cin"):
+        K.conv_forward(K.Sl(xin, cin, 0), wp, None, K.Sl(out), 3, math=K.MATH_BF16, center_cin=48)
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 35, 41), (1, 9, 33)])
 def test_conv_bf16_one_bit_relu_masks(K, N, H, W):
     """bits_mode 1 writes bit c = (stored output channel c > 0) per pixel; bits_mode 2 uses the word as the ReLU mask of the
