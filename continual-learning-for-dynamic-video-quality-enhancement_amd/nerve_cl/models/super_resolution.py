@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from nerve_cl import _engine, _nvq
+from nerve_cl import _engine, _graphs, _nvq
 from nerve_cl.models.layers import (
     CBAM,
     DepthwiseSeparableConv,
@@ -81,9 +81,18 @@ class _SRFunction(torch.autograd.Function):
     def forward(ctx, net: "SuperResolutionNet", frames: torch.Tensor, want_inter: bool, *params):
         P = net._tensor_dict()
         act = torch.bfloat16 if (net.bf16_activations and net.math_mode == _nvq.MATH_BF16) else torch.float32
-        out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode, act)
         need_grad = any(ctx.needs_input_grad[3:])
         ctx.net = net
+        ctx.graph = ctx.token = None
+        if net._graphs_wanted(frames) and not want_inter:
+            hit = net._step_graphs.forward(net, frames, need_grad, act)
+            if hit is not None:
+                out, entry, ctx.token, gen = hit
+                ctx.graph = (entry, gen) if need_grad else None
+                ctx.sv = None
+                net._last_intermediates = None
+                return out
+        out, sv = _engine.forward(P, frames, net._F, net._NB, net.scale_factor, net.training, net.math_mode, act)
         ctx.sv = sv if need_grad else None
         net._last_intermediates = _engine.intermediates(sv) if want_inter else None
         return out
@@ -91,16 +100,19 @@ class _SRFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         net, sv = ctx.net, ctx.sv
-        if sv is None:
-            raise RuntimeError("SuperResolutionNet backward called without saved forward state (a second backward through "
-                               "the same forward needs net.retain_backward_state = True, the analogue of retain_graph)")
         names = net._param_names
-        flat, views = net._new_grad_bucket()
-        _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
-        # A custom Function cannot see retain_graph, and the state of a 540p step is tens of GB that must not outlive the
-        # backward (autograd frees its own saved tensors here too), so it is dropped unless the module asks to keep it.
-        if not getattr(net, "retain_backward_state", False):
-            ctx.sv = None
+        if ctx.graph is not None:
+            flat, views = net._step_graphs.backward(net, ctx.graph[0], ctx.graph[1], dout)
+        else:
+            if sv is None:
+                raise RuntimeError("SuperResolutionNet backward called without saved forward state (a second backward through "
+                                   "the same forward needs net.retain_backward_state = True, the analogue of retain_graph)")
+            flat, views = net._new_grad_bucket()
+            _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
+            # A custom Function cannot see retain_graph, and the state of a 540p step is tens of GB that must not outlive
+            # the backward (autograd frees its own saved tensors here too), so it is dropped unless the module asks to keep it.
+            if not getattr(net, "retain_backward_state", False):
+                ctx.sv = None
         hook = net._grad_bucket_hook
         if hook is not None:
             hook(flat)           # data-parallel all-reduce of the whole bucket (nerve_cl.parallel)
@@ -148,6 +160,19 @@ class SuperResolutionNet(nn.Module):
         self._grad_bucket_hook = None
         self._last_intermediates = None
         self._last_grad_bucket = None
+        # HIP-graph replay of the step (nerve_cl/_graphs.py): True / False / "auto" = only for small frame sizes.  Off by
+        # default: measured on MI355X it frees the host thread but does not shorten the step (see _graphs.py).
+        # NVQ_GRAPH=1|0|auto sets the default for unmodified caller scripts.
+        env = os.environ.get("NVQ_GRAPH", "0").lower()
+        self.use_hip_graphs = True if env in ("1", "on", "true") else "auto" if env == "auto" else False
+        self._step_graphs = _graphs.StepGraphs()
+
+    GRAPH_AUTO_MAX_PIXELS = 8 * 3 * 128 * 128     # B*T*H*W up to which a step is launch-bound on MI355X
+
+    def _graphs_wanted(self, frames: torch.Tensor) -> bool:
+        if self.use_hip_graphs == "auto":
+            return frames.numel() // frames.shape[2] <= self.GRAPH_AUTO_MAX_PIXELS
+        return bool(self.use_hip_graphs)
 
     # ------------------------------------------------------------------ plumbing
     def _tensor_dict(self) -> Dict[str, torch.Tensor]:
@@ -163,13 +188,16 @@ class SuperResolutionNet(nn.Module):
             off += (p.numel() + 3) // 4 * 4
         return lay, off
 
+    def _bucket_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        lay, _ = self._bucket_layout()
+        shapes = {n: p.shape for n, p in self.named_parameters()}
+        return {n: flat[o:o + k].view(shapes[n]) for n, (o, k) in lay.items()}
+
     def _new_grad_bucket(self):
-        lay, total = self._bucket_layout()
+        _, total = self._bucket_layout()
         dev = next(self.parameters()).device
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        shapes = {n: p.shape for n, p in self.named_parameters()}
-        views = {n: flat[o:o + k].view(shapes[n]) for n, (o, k) in lay.items()}
-        return flat, views
+        return flat, self._bucket_views(flat)
 
     # ------------------------------------------------------------------ reference API
     def forward(self, lr_frames: torch.Tensor, return_intermediate: bool = False):
@@ -252,7 +280,7 @@ class _LightFunction(torch.autograd.Function):
         net, sv = ctx.net, ctx.sv
         if sv is None:
             raise RuntimeError("LightweightSuperResolution backward called without saved forward state")
-        flat, views = SuperResolutionNet._new_grad_bucket(net)
+        flat, views = net._new_grad_bucket()
         _engine.light_backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
         if not getattr(net, "retain_backward_state", False):
             ctx.sv = None
@@ -284,6 +312,8 @@ class LightweightSuperResolution(nn.Module):
 
     _tensor_dict = SuperResolutionNet._tensor_dict
     _bucket_layout = SuperResolutionNet._bucket_layout
+    _bucket_views = SuperResolutionNet._bucket_views
+    _new_grad_bucket = SuperResolutionNet._new_grad_bucket
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> (B,3,H*s,W*s)."""
