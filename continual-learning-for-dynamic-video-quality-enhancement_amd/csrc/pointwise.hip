@@ -103,6 +103,109 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------- head conv on the matrix cores (NVQ_MATH_BF16, 3 channels)
+// The 27-term contraction of the 3 -> F head conv as v_mfma_f32_16x16x32_bf16: K index k = dy*12 + dx*4 + ci over a halo
+// tile staged in LDS as bf16 [18][66][4] (3 channels + a zero: 8 B per pixel), so that a lane's 8 consecutive k are two
+// 8-byte pieces = two pixels of the tile; k = 32..35 (the last pixel of the window) takes a second MFMA whose other
+// operands are zero.  Output rows are PERMUTED: row i of block cb is channel (i/4)*(F/4) + 4*cb + i%4, so lane (pixel c,
+// group g) ends up with the F/4 consecutive channels [g*F/4, (g+1)*F/4) of its pixel and stores them as 16-byte pieces.
+// The fp32 kernel above issues 27 FMAs per 4 outputs and ran at 0.95 TB/s of output; this one is bound by its stores.
+constexpr int HM_TH = 16, HM_TW = 64, HM_HW = HM_TW + 2, HM_HH = HM_TH + 2;
+
+template <int NB>
+__global__ __launch_bounds__(256) void head_mfma_kernel(const float* __restrict__ frames, int B, int T, int H, int W,
+                                                        SlotMap sm, const float* __restrict__ weight,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int out_ld,
+                                                        int out_bf16, __bf16* __restrict__ img8, int tilesX, int tilesY) {
+    constexpr int F = 16 * NB, FQ = F / 4;
+    __shared__ __attribute__((aligned(16))) bf16x4 xs[HM_HH * HM_HW + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    int bt = blockIdx.x;
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int slot = n / B, b = n - slot * B;
+    const float* img = frames + ((size_t)(b * T + sm.t[slot]) * 3) * H * W;
+
+    // weights: A fragments of both K steps, kept for the whole tile
+    auto wk = [&](int co, int k) -> float {
+        const int dy = k / 12, j = k - dy * 12, dx = j >> 2, ci = j & 3;
+        return (k < 36 && ci < 3) ? weight[co * 27 + ci * 9 + dy * 3 + dx] : 0.f;
+    };
+    bf16x8 a0[NB], a1[NB];
+    float4 bv[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        const int co = (c >> 2) * FQ + 4 * cb + (c & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a0[cb][e] = (__bf16)wk(co, 8 * g + e);
+            a1[cb][e] = (__bf16)wk(co, 32 + 8 * g + e);
+        }
+        bv[cb] = ld4(bias + g * FQ + 4 * cb);
+    }
+    // halo tile -> LDS
+    for (int item = tid; item < HM_HH * HM_HW; item += 256) {
+        const int hy = item / HM_HW, hx = item - hy * HM_HW;
+        const int gy = ty * HM_TH + hy - 1, gx = tx * HM_TW + hx - 1;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = ok ? (size_t)gy * W + gx : 0;
+        const float v0 = img[o], v1 = img[(size_t)H * W + o], v2 = img[(size_t)2 * H * W + o];
+        xs[item] = ok ? (bf16x4){(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)0.f}
+                      : (bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    }
+    __syncthreads();
+    // pixel offsets (in pixels, relative to the window's top-left) of this lane's two 8-byte pieces of K step 0
+    const int o0 = g == 0 ? 0 : g == 1 ? 2 : g == 2 ? HM_HW + 1 : 2 * HM_HW;
+    const int o1 = g == 0 ? 1 : g == 1 ? HM_HW : g == 2 ? HM_HW + 2 : 2 * HM_HW + 1;
+    const bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll 2
+    for (int k = 0; k < 16; ++k) {
+        const int bi = wave * 16 + k;
+        const int ry = bi >> 2, xb = (bi & 3) * 16;
+        const int base = ry * HM_HW + xb + c;
+        const bf16x4 p0 = xs[base + o0], p1 = xs[base + o1];
+        const bf16x4 p2 = g == 0 ? xs[base + 2 * HM_HW + 2] : z4;
+        const bf16x8 b0 = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        const bf16x8 b1 = {p2[0], p2[1], p2[2], p2[3], z4[0], z4[1], z4[2], z4[3]};
+        const int gy = ty * HM_TH + ry, gx = tx * HM_TW + xb + c;
+        const bool ok = gy < H && gx < W;
+        const size_t pix = (size_t)(n * H + gy) * W + gx;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            acc[cb] = (f32x4){bv[cb].x, bv[cb].y, bv[cb].z, bv[cb].w};
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[cb], b0, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[cb], b1, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[cb][e] = fmaxf(acc[cb][e], 0.f);
+        }
+        if (ok) {
+            if (out_bf16) {
+                __bf16* o16 = reinterpret_cast<__bf16*>(out) + pix * out_ld + g * FQ;
+                if constexpr (NB == 1) {
+                    *reinterpret_cast<bf16x4*>(o16) = (bf16x4){(__bf16)acc[0][0], (__bf16)acc[0][1], (__bf16)acc[0][2], (__bf16)acc[0][3]};
+                } else {
+#pragma unroll
+                    for (int cb = 0; cb < NB; cb += 2)
+                        *reinterpret_cast<bf16x8*>(o16 + 4 * cb) =
+                            (bf16x8){(__bf16)acc[cb][0], (__bf16)acc[cb][1], (__bf16)acc[cb][2], (__bf16)acc[cb][3],
+                                     (__bf16)acc[cb + 1][0], (__bf16)acc[cb + 1][1], (__bf16)acc[cb + 1][2], (__bf16)acc[cb + 1][3]};
+                }
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb)
+                    st4(out + pix * out_ld + g * FQ + 4 * cb, make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]));
+            }
+            if (img8 && g == 0) {                          // the frame itself as bf16 NHWC-8 (slot order), see nvq.h
+                const bf16x4 px = xs[base + HM_HW + 1];
+                *reinterpret_cast<bf16x8*>(img8 + pix * 8) = (bf16x8){px[0], px[1], px[2], z4[0], z4[0], z4[0], z4[0], z4[0]};
+            }
+        }
+    }
+}
+
 // Cross pixel-lane reduction of a float4 inside a 256-thread block whose threads are laid out
 // as (pixel lane, c4) with C4 lanes per pixel.  Threads with pixel lane 0 get the sum.
 __device__ __forceinline__ float4 plane_reduce4(float4 v, float4* buf, int C4, int npl) {
@@ -774,35 +877,48 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
     invstd[i] = 1.f / sqrtf(rvar[c] + eps);
 }
 
+// The two element-wise BatchNorm passes: grid (blocks, groups), EW_ITEMS 4-channel pieces per thread, all 32-bit index
+// arithmetic (the first versions spent their time in three 64-bit divisions per 8-byte load: 3.6 TB/s; the reduce kernels,
+// which loop without dividing, ran at 5).  256 % (C/4) == 0, so a thread's pieces all have the same channels and the
+// per-channel constants are loaded once.
+constexpr int EW_ITEMS = 4;
+
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
-    const float* __restrict__ x, int x_ld, int C, long img_pix, int group_images,
+    const float* __restrict__ x, int x_ld, int C, int c4_shift, unsigned group_items, long group_pix,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, int res_ld, float* __restrict__ outA,
-    int outA_ld, int outA_coff, int split_images, float* __restrict__ outB, int outB_ld, int outB_coff,
-    int x_bf16, int out_bf16, int res_bf16, long total) {
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= total) return;
-    const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int n = pix / img_pix;
-    const int g = n / group_images;
-    const float4 v = ldx4(x, (size_t)pix * x_ld + 4 * c4, x_bf16);
+    int outA_ld, int outA_coff, long split_pix, float* __restrict__ outB, int outB_ld, int outB_coff,
+    int x_bf16, int out_bf16, int res_bf16) {
+    const int g = blockIdx.y;
+    const int c4 = threadIdx.x & ((C >> 2) - 1);
     const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
     const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
-    float4 y;
-    y.x = fmaxf((v.x - m.x) * is.x * ga.x + be.x, 0.f);
-    y.y = fmaxf((v.y - m.y) * is.y * ga.y + be.y, 0.f);
-    y.z = fmaxf((v.z - m.z) * is.z * ga.z + be.z, 0.f);
-    y.w = fmaxf((v.w - m.w) * is.w * ga.w + be.w, 0.f);
-    if (res) {
-        const float4 r = ldx4(res, (size_t)pix * res_ld + 4 * c4, res_bf16);
-        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    const long base = (long)g * group_pix;
+    float4 v[EW_ITEMS], r[EW_ITEMS];
+    long pix[EW_ITEMS];
+    bool ok[EW_ITEMS];
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const unsigned i = (blockIdx.x * EW_ITEMS + k) * 256u + threadIdx.x;
+        ok[k] = i < group_items;
+        pix[k] = base + (ok[k] ? (i >> c4_shift) : 0u);
+        v[k] = ldx4(x, (size_t)pix[k] * x_ld + 4 * c4, x_bf16);
+        r[k] = res ? ldx4(res, (size_t)pix[k] * res_ld + 4 * c4, res_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (n < split_images)
-        stx4(outA, (size_t)pix * outA_ld + outA_coff + 4 * c4, out_bf16, y);
-    else
-        stx4(outB, (size_t)(pix - (long)split_images * img_pix) * outB_ld + outB_coff + 4 * c4, out_bf16, y);
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        float4 y;
+        y.x = fmaxf((v[k].x - m.x) * is.x * ga.x + be.x, 0.f);
+        y.y = fmaxf((v[k].y - m.y) * is.y * ga.y + be.y, 0.f);
+        y.z = fmaxf((v[k].z - m.z) * is.z * ga.z + be.z, 0.f);
+        y.w = fmaxf((v[k].w - m.w) * is.w * ga.w + be.w, 0.f);
+        if (res) { y.x += r[k].x; y.y += r[k].y; y.z += r[k].z; y.w += r[k].w; }
+        if (!ok[k]) continue;
+        if (pix[k] < split_pix)
+            stx4(outA, (size_t)pix[k] * outA_ld + outA_coff + 4 * c4, out_bf16, y);
+        else
+            stx4(outB, (size_t)(pix[k] - split_pix) * outB_ld + outB_coff + 4 * c4, out_bf16, y);
+    }
 }
 
 // backward pass 1: part[g][blk][2C] = {sum dyr, sum dyr*xhat}, dyr = dy * [bn(x) > 0]
@@ -870,18 +986,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C, long img_pix,
-    int group_images, long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C, int c4_shift,
+    unsigned group_items, long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
-    int training, float* __restrict__ dx, int dx_ld, int dy_bf16, int x_bf16, int dx_bf16, long total) {
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= total) return;
-    const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int g = (pix / img_pix) / group_images;
-    const float4 v = ldx4(x, (size_t)pix * x_ld + 4 * c4, x_bf16);
-    const float4 d0 = ldx4(dy, (size_t)pix * dy_ld + 4 * c4, dy_bf16);
+    int training, float* __restrict__ dx, int dx_ld, int dy_bf16, int x_bf16, int dx_bf16) {
+    const int g = blockIdx.y;
+    const int c4 = threadIdx.x & ((C >> 2) - 1);
     const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
     const float4 ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -890,18 +1000,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         s2 = ld4(sums + (size_t)g * 2 * C + C + 4 * c4);
     }
     const float inv_n = 1.f / (float)group_pix;
-    float dv[4] = {d0.x, d0.y, d0.z, d0.w};
-    const float xv[4] = {v.x, v.y, v.z, v.w}, mv[4] = {m.x, m.y, m.z, m.w}, iv[4] = {is.x, is.y, is.z, is.w};
+    const float mv[4] = {m.x, m.y, m.z, m.w}, iv[4] = {is.x, is.y, is.z, is.w};
     const float gv[4] = {ga.x, ga.y, ga.z, ga.w}, bv[4] = {be.x, be.y, be.z, be.w};
     const float a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
-    float o[4];
+    const long base = (long)g * group_pix;
+    float4 v[EW_ITEMS], d0[EW_ITEMS];
+    long pix[EW_ITEMS];
+    bool ok[EW_ITEMS];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float h = (xv[e] - mv[e]) * iv[e];
-        const float d = (h * gv[e] + bv[e] > 0.f) ? dv[e] : 0.f;
-        o[e] = training ? gv[e] * iv[e] * (d - a1[e] * inv_n - h * a2[e] * inv_n) : gv[e] * iv[e] * d;
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const unsigned i = (blockIdx.x * EW_ITEMS + k) * 256u + threadIdx.x;
+        ok[k] = i < group_items;
+        pix[k] = base + (ok[k] ? (i >> c4_shift) : 0u);
+        v[k] = ldx4(x, (size_t)pix[k] * x_ld + 4 * c4, x_bf16);
+        d0[k] = ldx4(dy, (size_t)pix[k] * dy_ld + 4 * c4, dy_bf16);
     }
-    stx4(dx, (size_t)pix * dx_ld + 4 * c4, dx_bf16, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int k = 0; k < EW_ITEMS; ++k) {
+        const float xv[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, dv[4] = {d0[k].x, d0[k].y, d0[k].z, d0[k].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = (xv[e] - mv[e]) * iv[e];
+            const float d = (h * gv[e] + bv[e] > 0.f) ? dv[e] : 0.f;
+            o[e] = training ? gv[e] * iv[e] * (d - a1[e] * inv_n - h * a2[e] * inv_n) : gv[e] * iv[e] * d;
+        }
+        if (ok[k]) stx4(dx, (size_t)pix[k] * dx_ld + 4 * c4, dx_bf16, make_float4(o[0], o[1], o[2], o[3]));
+    }
 }
 
 // ---------------------------------------------------------------- slice axpy
@@ -952,18 +1077,33 @@ extern "C" {
 
 int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      const int* t_of_slot_host, int nslots, const float* weight, const float* bias,
-                     int F, float* out, int out_ld, int out_bf16, float* img8, void* stream) {
+                     int F, float* out, int out_ld, int out_bf16, float* img8, int math, void* stream) {
     NVQ_REQUIRE(Cin == 3 || Cin == 1, "head_forward: in_channels %d not supported (1 or 3)", Cin);
     NVQ_REQUIRE(pow2_c4(F) && out_ld % 4 == 0 && aligned16(out), "head_forward: F %d (power of two in [4,256]) / ld %d", F, out_ld);
     NVQ_REQUIRE(nslots >= 1 && nslots <= NVQ_MAX_T && T <= NVQ_MAX_T, "head_forward: T %d slots %d", T, nslots);
     SlotMap sm;
     for (int i = 0; i < NVQ_MAX_T; ++i) sm.t[i] = i < nslots ? t_of_slot_host[i] : 0;
+    NVQ_REQUIRE(math == NVQ_MATH_F32 || math == NVQ_MATH_BF16, "head_forward: math mode %d", math);
+    NVQ_REQUIRE(!out_bf16 || out_ld % 8 == 0, "head_forward: a bf16 output needs ld %% 8 == 0 (%d)", out_ld);
+    hipStream_t s = (hipStream_t)stream;
+    if (math == NVQ_MATH_BF16 && Cin == 3 && (F == 16 || F == 32 || F == 64)) {
+        const int tilesX = (W + HM_TW - 1) / HM_TW, tilesY = (H + HM_TH - 1) / HM_TH;
+        const long nwg = (long)tilesX * tilesY * nslots * B;
+        NVQ_REQUIRE(nwg < ((long)1 << 31), "head_forward: too many tiles");
+        __bf16* i8 = reinterpret_cast<__bf16*>(img8);
+#define NVQ_HEAD_MFMA(NB) hipLaunchKernelGGL((head_mfma_kernel<NB>), dim3((unsigned)nwg), dim3(256), 0, s, frames, B, T, H, W, \
+                                             sm, weight, bias, out, out_ld, out_bf16, i8, tilesX, tilesY)
+        if (F == 16) NVQ_HEAD_MFMA(1);
+        else if (F == 32) NVQ_HEAD_MFMA(2);
+        else NVQ_HEAD_MFMA(4);
+#undef NVQ_HEAD_MFMA
+        return check_launch("head_forward(mfma)");
+    }
     const int segsX = (W + HEAD_SEG - 1) / HEAD_SEG;
     const long nseg = (long)nslots * B * H * segsX;
     const int npl = 256 / (F / 4);
     int nblk = ceil_div(nseg, npl);
     if (nblk > 2048) nblk = 2048;
-    hipStream_t s = (hipStream_t)stream;
     if (Cin == 3)
         hipLaunchKernelGGL((head_fwd_kernel<3>), dim3(nblk), dim3(256), 0, s, frames, B, T, H, W, sm, weight, bias, F, out, out_ld, out_bf16, reinterpret_cast<__bf16*>(img8), nseg, segsX);
     else
@@ -1126,10 +1266,18 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
                     outB_coff % 4 == 0 && (!res || res_ld % 4 == 0),
                 "bn_apply_relu: alignment");
     NVQ_REQUIRE(split_images >= N || outB, "bn_apply_relu: outB missing");
-    const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
-                       C, (long)H * W, group_images, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld,
-                       outA_coff, split_images, outB, outB_ld, outB_coff, x_bf16, out_bf16, res_bf16, total);
+    NVQ_REQUIRE(pow2_c4(C), "bn_apply_relu: C %d must be a power of two in [4,256]", C);
+    NVQ_REQUIRE(group_images > 0 && N % group_images == 0, "bn_apply_relu: groups");
+    const int G = N / group_images;
+    const long group_pix = (long)group_images * H * W;
+    NVQ_REQUIRE(group_pix * (C / 4) < ((long)1 << 32) - 256 * EW_ITEMS, "bn_apply_relu: group of %ld pixels too large", group_pix);
+    int shift = 0;
+    while ((1 << shift) < C / 4) ++shift;
+    const unsigned items = (unsigned)(group_pix * (C / 4));
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div((long)items, 256 * EW_ITEMS), G), dim3(256), 0, (hipStream_t)stream,
+                       x, x_ld, C, shift, items, group_pix, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld, outA_coff,
+                       (long)(split_images < N ? split_images : N) * H * W, outB, outB_ld, outB_coff, x_bf16, out_bf16,
+                       res_bf16);
     return check_launch("bn_apply_relu");
 }
 
@@ -1156,10 +1304,13 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
                        dgamma, dbeta, accumulate);
     rc = check_launch("bn_bwd_finalize");
     if (rc) return rc;
-    const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dy, dy_ld, x, x_ld, C,
-                       (long)H * W, group_images, group_pix, mean, invstd, gamma, beta, sums, training, dx, dx_ld,
-                       dy_bf16, x_bf16, dx_bf16, total);
+    NVQ_REQUIRE(group_pix * (C / 4) < ((long)1 << 32) - 256 * EW_ITEMS, "bn_relu_backward: group of %ld pixels too large", group_pix);
+    int shift = 0;
+    while ((1 << shift) < C / 4) ++shift;
+    const unsigned items = (unsigned)(group_pix * (C / 4));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div((long)items, 256 * EW_ITEMS), G), dim3(256), 0, s, dy, dy_ld, x,
+                       x_ld, C, shift, items, group_pix, mean, invstd, gamma, beta, sums, training, dx, dx_ld, dy_bf16,
+                       x_bf16, dx_bf16);
     return check_launch("bn_bwd_apply");
 }
 

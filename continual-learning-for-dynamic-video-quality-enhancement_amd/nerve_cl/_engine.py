@@ -85,7 +85,7 @@ def _extract(P: Dict[str, torch.Tensor], frames: torch.Tensor, slots, F: int, tr
     # bf16 mode: the head's weight gradient runs on the matrix cores (conv_wgrad over the frames as bf16 NHWC-8)
     sv.img8 = _new(dev, NI, H, W, 8, dtype=torch.bfloat16) if (training and K.dwconv_bn_fusable(feat0, F)) else None
     K.head_forward(frames, slots, P["feature_extractor.head.0.weight"], P["feature_extractor.head.0.bias"], feat0,
-                   img8=sv.img8)
+                   img8=sv.img8, math=math)
     sv.feat0 = feat0
     sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = [], [], [], [], []
     cur, cur_bn = feat0, None         # cur_bn: BatchNorm + ReLU still to be applied to `cur` (fused into the consumer)
@@ -446,7 +446,7 @@ def light_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, scale: int, train
     sv = Saved()
     sv.frames, sv.training, sv.math, sv.act_dtype, sv.scale = frames, training, math, act_dtype, scale
     feat0 = _new(dev, B, H, W, F, dtype=act_dtype)
-    K.head_forward(frames, [0], P["net.0.weight"], P["net.0.bias"], feat0)
+    K.head_forward(frames, [0], P["net.0.weight"], P["net.0.bias"], feat0, math=math)
     sv.feat0, sv.dws, sv.pws, sv.acts, sv.bn_mean, sv.bn_invstd = feat0, [], [], [], [], []
     cur = feat0
     for k in LIGHT_BLOCKS:

@@ -82,7 +82,7 @@ SIGNATURES = {
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
-    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp, vp]),
+    "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp, ci, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
     "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_dwconv_wgrad": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, ci, ci, vp, vp]),
@@ -419,12 +419,12 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
 
 # ----------------------------------------------------------------------------- feature extractor
 def head_forward(frames: torch.Tensor, slots: Sequence[int], weight, bias, out: torch.Tensor,
-                 img8: Optional[torch.Tensor] = None) -> None:
+                 img8: Optional[torch.Tensor] = None, math: int = MATH_F32) -> None:
     B, T, Cin, H, W = frames.shape
     F = weight.shape[0]
     assert img8 is None or (img8.dtype == torch.bfloat16 and tuple(img8.shape) == (len(slots) * B, H, W, 8))
     check(lib().nvq_head_forward(ptr(frames), B, T, Cin, H, W, int_array(slots), len(slots), ptr(weight),
-                                 ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), ptr(img8), stream()),
+                                 ptr(bias), F, ptr(out), out.shape[-1], is_bf16(out), ptr(img8), math, stream()),
           "nvq_head_forward")
 
 
