@@ -279,7 +279,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     du = _new(dev, B, H, W, g.Up)
     K.shuffle_clamp_backward(dout, sv.passmask, g.s, du)
     _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", ws, 3, math=math)
-    dfeat_all = _new(dev, NI, H, W, F, zero=True)   # gradient w.r.t. the features of every frame (slot order)
+    dfeat_all = _new(dev, NI, H, W, F)              # gradient w.r.t. the features of every frame (slot order)
+    dfeat_all[B:].zero_()                           # the centre frames' part is first written (out2 below), the rest added to
     dfeat_c = dfeat_all[:B]
     dg = _new(dev, B, H, W, F)
     K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
