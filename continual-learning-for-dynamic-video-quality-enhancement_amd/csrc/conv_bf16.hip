@@ -44,30 +44,42 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 
 // ---------------------------------------------------------------- weight packing (bf16)
 // wpack[cz][kc][tap][g][n][j] (g = 0..3, n = 0..NT-1, j = 0..7) = bf16(W[cout = cz*NT + n][ch = kc*32 + 8g + j][tap])
+__device__ __forceinline__ __bf16 pack_bf16_elem(const float* __restrict__ w, int cout_w, int cin_w, int taps, int transpose,
+                                                 int cout_keep, int NT, int nkc, long idx) {
+    const int stride = ws_stride_halfs(taps, NT);
+    long t = idx % stride;
+    const long slab = idx / stride;
+    if (t >= (long)taps * 4 * NT * 8) return (__bf16)0.f;
+    const int j = t & 7; t >>= 3;
+    const int n = t % NT; t /= NT;
+    const int g = t & 3; t >>= 2;
+    const int tap = (int)t;
+    const int kc = slab % nkc;
+    const int cz = (int)(slab / nkc);
+    const int co = cz * NT + n;
+    const int ch = kc * KCB + 8 * g + j;
+    float v = 0.f;
+    if (!transpose) {
+        if (co < cout_w && ch < cin_w) v = w[((long)co * cin_w + ch) * taps + tap];
+    } else {
+        if (co < cout_keep && ch < cout_w) v = w[((long)ch * cin_w + co) * taps + (taps - 1 - tap)];
+    }
+    return (__bf16)v;
+}
+
 __global__ void pack_bf16_kernel(const float* __restrict__ w, int cout_w, int cin_w, int taps, int transpose,
                                  int cout_keep, int NT, int ncz, int nkc, __bf16* __restrict__ wp) {
-    const int stride = ws_stride_halfs(taps, NT);
-    const long total = (long)ncz * nkc * stride;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        long t = idx % stride;
-        const long slab = idx / stride;
-        if (t >= (long)taps * 4 * NT * 8) { wp[idx] = (__bf16)0.f; continue; }
-        const int j = t & 7; t >>= 3;
-        const int n = t % NT; t /= NT;
-        const int g = t & 3; t >>= 2;
-        const int tap = (int)t;
-        const int kc = slab % nkc;
-        const int cz = (int)(slab / nkc);
-        const int co = cz * NT + n;
-        const int ch = kc * KCB + 8 * g + j;
-        float v = 0.f;
-        if (!transpose) {
-            if (co < cout_w && ch < cin_w) v = w[((long)co * cin_w + ch) * taps + tap];
-        } else {
-            if (co < cout_keep && ch < cout_w) v = w[((long)ch * cin_w + co) * taps + (taps - 1 - tap)];
-        }
-        wp[idx] = (__bf16)v;
-    }
+    const long total = (long)ncz * nkc * ws_stride_halfs(taps, NT);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+        wp[idx] = pack_bf16_elem(w, cout_w, cin_w, taps, transpose, cout_keep, NT, nkc, idx);
+}
+
+// grid (blocks, jobs): nvq_conv_pack_batch
+__global__ void pack_batch_bf16_kernel(const PackJobTable t) {
+    const PackJobDev j = t.j[blockIdx.y];
+    __bf16* wp = reinterpret_cast<__bf16*>(j.wp);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < j.total; idx += (long)gridDim.x * blockDim.x)
+        wp[idx] = pack_bf16_elem(j.w, j.cout_w, j.cin_w, j.taps, j.transpose, j.cout_keep, j.NT, j.nkc, idx);
 }
 
 // ---------------------------------------------------------------- forward / input gradient
@@ -731,6 +743,19 @@ int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, i
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(nblk), dim3(256), 0, s, w, cout_w, cin_w, ksize * ksize, transpose,
                        cout_keep, NT, ncz, nkc, reinterpret_cast<__bf16*>(wpack));
     return check_launch("conv_pack_bf16");
+}
+
+PackJobDev pack_job_bf16(const nvq_pack_job& j) {
+    const int cout = j.transpose ? j.cout_keep : j.cout_w;
+    const int NT = choose_nt(cout);
+    const int ncz = (cout + NT - 1) / NT, nkc = (j.cin_store + KCB - 1) / KCB;
+    return PackJobDev{j.w, j.wpack, j.cout_w, j.cin_w, j.ksize * j.ksize, j.transpose, j.cout_keep, NT, ncz, nkc,
+                      (long)ncz * nkc * ws_stride_halfs(j.ksize * j.ksize, NT)};
+}
+
+int pack_batch_bf16(const PackJobTable& t, int n, hipStream_t s) {
+    hipLaunchKernelGGL(pack_batch_bf16_kernel, dim3(32, n), dim3(256), 0, s, t);
+    return check_launch("conv_pack_batch(bf16)");
 }
 
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {

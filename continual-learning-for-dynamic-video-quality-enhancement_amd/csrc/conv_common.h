@@ -18,6 +18,13 @@ void set_conv_debug_mode(int m);
 size_t pack_floats_bf16(int cout, int cin_store, int ksize);
 int pack_bf16(const float* w, int cout_w, int cin_w, int ksize, int transpose, int cin_store, int cout_keep,
               float* wpack, hipStream_t s);
+// One job of a batched pack launch (nvq_conv_pack_batch), in kernel-argument form; total = elements of the packed buffer
+// (floats in the fp32 layout, bf16 values in the bf16 layout).
+struct PackJobDev { const float* w; float* wp; int cout_w, cin_w, taps, transpose, cout_keep, NT, ncz, nkc; long total; };
+constexpr int PACK_BATCH = 48;                      // jobs per launch (the table travels as a kernel argument, < 4 KB)
+struct PackJobTable { PackJobDev j[PACK_BATCH]; };
+int pack_batch_bf16(const PackJobTable& t, int n, hipStream_t s);
+PackJobDev pack_job_bf16(const nvq_pack_job& j);
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s);

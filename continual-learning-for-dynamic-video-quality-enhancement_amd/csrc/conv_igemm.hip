@@ -17,29 +17,40 @@ constexpr int XS_LD = 20;  // floats per staged pixel (16 + 4 pad: the 16 pixels
 // ---------------------------------------------------------------- weight packing
 // wpack[cz][kc][tap][g][n][j]  (g = 0..3 lane group, n = 0..NT-1, j = 0..3) holds
 // W[cout = cz*NT + n][channel = kc*16 + 4g + j][tap]; zero outside the real extents.
+__device__ __forceinline__ float pack_f32_elem(const float* __restrict__ w, int cout_w, int cin_w, int taps, int transpose,
+                                               int cout_keep, int NT, int nkc, long idx) {
+    long t = idx;
+    const int j = t & 3; t >>= 2;
+    const int n = t % NT; t /= NT;
+    const int g = t & 3; t >>= 2;
+    const int tap = t % taps; t /= taps;
+    const int kc = t % nkc; t /= nkc;
+    const int cz = (int)t;
+    const int co = cz * NT + n;
+    const int ch = kc * KC + 4 * g + j;
+    float v = 0.f;
+    if (!transpose) {
+        if (co < cout_w && ch < cin_w) v = w[((long)co * cin_w + ch) * taps + tap];
+    } else {
+        if (co < cout_keep && ch < cout_w) v = w[((long)ch * cin_w + co) * taps + (taps - 1 - tap)];
+    }
+    return v;
+}
+
 __global__ void pack_kernel(const float* __restrict__ w, int cout_w, int cin_w, int taps,
                             int transpose, int cout_keep, int NT, int ncz, int nkc,
                             float* __restrict__ wp) {
     const long total = (long)ncz * nkc * taps * 4 * NT * 4;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        long t = idx;
-        const int j = t & 3; t >>= 2;
-        const int n = t % NT; t /= NT;
-        const int g = t & 3; t >>= 2;
-        const int tap = t % taps; t /= taps;
-        const int kc = t % nkc; t /= nkc;
-        const int cz = (int)t;
-        const int co = cz * NT + n;
-        const int ch = kc * KC + 4 * g + j;
-        float v = 0.f;
-        if (!transpose) {
-            if (co < cout_w && ch < cin_w) v = w[((long)co * cin_w + ch) * taps + tap];
-        } else {
-            if (co < cout_keep && ch < cout_w) v = w[((long)ch * cin_w + co) * taps + (taps - 1 - tap)];
-        }
-        wp[idx] = v;
-    }
+         idx += (long)gridDim.x * blockDim.x)
+        wp[idx] = pack_f32_elem(w, cout_w, cin_w, taps, transpose, cout_keep, NT, nkc, idx);
+}
+
+// grid (blocks, jobs): nvq_conv_pack_batch
+__global__ void pack_batch_kernel(const PackJobTable t) {
+    const PackJobDev j = t.j[blockIdx.y];
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < j.total; idx += (long)gridDim.x * blockDim.x)
+        j.wp[idx] = pack_f32_elem(j.w, j.cout_w, j.cin_w, j.taps, j.transpose, j.cout_keep, j.NT, j.nkc, idx);
 }
 
 // ---------------------------------------------------------------- dense-block backward weights
@@ -401,6 +412,47 @@ int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpos
     hipLaunchKernelGGL(pack_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, w, cout_w, cin_w,
                        ksize * ksize, transpose, cout_keep, NT, ncz, nkc, wpack);
     return check_launch("conv_pack");
+}
+
+int nvq_conv_pack_batch(const nvq_pack_job* jobs, int njobs, int math, void* stream) {
+    NVQ_REQUIRE(njobs >= 0 && (njobs == 0 || jobs), "conv_pack_batch: %d jobs", njobs);
+    NVQ_REQUIRE(math == NVQ_MATH_F32 || math == NVQ_MATH_BF16, "conv_pack_batch: math mode %d", math);
+    for (int i = 0; i < njobs; ++i) {                        // the checks of nvq_conv_pack, for every job, before any launch
+        const nvq_pack_job& j = jobs[i];
+        NVQ_REQUIRE(j.ksize == 1 || j.ksize == 3, "conv_pack_batch[%d]: ksize %d", i, j.ksize);
+        const int cin_real = j.transpose ? j.cout_w : j.cin_w;
+        NVQ_REQUIRE(j.cin_store >= cin_real && j.cin_store % 4 == 0, "conv_pack_batch[%d]: cin_store %d < %d or not %%4", i,
+                    j.cin_store, cin_real);
+        NVQ_REQUIRE(!j.transpose || j.cout_keep <= j.cin_w, "conv_pack_batch[%d]: cout_keep %d > cin_w %d", i, j.cout_keep,
+                    j.cin_w);
+        NVQ_REQUIRE(j.w && j.wpack, "conv_pack_batch[%d]: null pointer", i);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < njobs; base += PACK_BATCH) {
+        const int n = njobs - base < PACK_BATCH ? njobs - base : PACK_BATCH;
+        PackJobTable t{};
+        for (int i = 0; i < n; ++i) {
+            const nvq_pack_job& j = jobs[base + i];
+            if (math == NVQ_MATH_BF16) {
+                t.j[i] = pack_job_bf16(j);
+            } else {
+                const int cout = j.transpose ? j.cout_keep : j.cout_w;
+                const int NT = choose_nt(cout);
+                const int ncz = (cout + NT - 1) / NT, nkc = (j.cin_store + KC - 1) / KC;
+                t.j[i] = PackJobDev{j.w, j.wpack, j.cout_w, j.cin_w, j.ksize * j.ksize, j.transpose, j.cout_keep, NT, ncz, nkc,
+                                    (long)ncz * nkc * j.ksize * j.ksize * 4 * NT * 4};
+            }
+        }
+        if (math == NVQ_MATH_BF16) {
+            const int rc = pack_batch_bf16(t, n, s);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(pack_batch_kernel, dim3(32, n), dim3(256), 0, s, t);
+            const int rc = check_launch("conv_pack_batch");
+            if (rc) return rc;
+        }
+    }
+    return NVQ_OK;
 }
 
 size_t nvq_rdb_backward_weights_floats(int F) { return (size_t)9 * (32 * (5 * F + 320) + (size_t)F * (F + 160)); }

@@ -300,28 +300,34 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.TIMER_TAG = "rdb"
     # the gout channels of the mirror-form convs only carry the 1x1 lff^T term: the bf16 kernels skip their other taps
     ctr = F if (math == K.MATH_BF16 and F % 32 == 0) else 0
+    # the combined weights of all blocks, then their 6 * nb packs in one launch
+    reqs = []
+    for k in range(nb):
+        pre = f"residual_blocks.{k}."
+        wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
+        reqs += [(wb[j], False, F + GROWTH * j, None) for j in range(LAYERS)] + [(wbx, False, g.CAT, None)]
+    mirror = K.conv_pack_many(reqs, math)
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
         gout = Sl(dcat, F, 0)
         _wgrad(Sl(cat, g.CAT, 0), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
-        wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
+        wpb = mirror[k * (LAYERS + 1):(k + 1) * (LAYERS + 1)]     # packs of Wb_4 .. Wb_0, Wb_x
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
             dy = Sl(dcat, GROWTH, cinb)                      # slot of dy_i
             if sv.bits is not None:
-                K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
+                K.conv_forward(Sl(dcat, cinb, 0), wpb[LAYERS - 1 - i], None, dy, 3,
                                math=math, bits=sv.bits[k][i], bits_mode=2, center_cin=ctr)
             else:
-                K.conv_forward(Sl(dcat, cinb, 0), K.conv_pack(wb[LAYERS - 1 - i], False, cinb, math=math), None, dy, 3,
+                K.conv_forward(Sl(dcat, cinb, 0), wpb[LAYERS - 1 - i], None, dy, 3,
                                mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
             cin = F + GROWTH * i
             _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
         nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
-        K.conv_forward(Sl(dcat, g.CAT, 0), K.conv_pack(wbx, False, g.CAT, math=math), None, nxt, 3, res=gout, math=math,
-                       center_cin=ctr)
+        K.conv_forward(Sl(dcat, g.CAT, 0), wpb[LAYERS], None, nxt, 3, res=gout, math=math, center_cin=ctr)
     K.TIMER_TAG = ""
     dprev = Sl(dagg)
 

@@ -8,9 +8,9 @@ replayed from then on: one graph launch instead of hundreds of kernel launches.
 
 Measured (tools/graph_bench.py, MI355X, ROCm 7.2): the replayed step takes exactly as long as the eager one (8 clips of
 64x64, F=64, 8 blocks: 13.0 ms either way; 128x128: 27.0 vs 26.8 ms), with identical results.  The small-frame step is
-bound by the device-side latency of ~700 dependent dispatches (~18 us each), which a graph replay on this runtime does not
-shorten; what it saves is the host thread (one call per pass instead of ~700 ctypes calls).  It is therefore OFF by default
-(``net.use_hip_graphs = True`` or ``NVQ_GRAPH=1`` to enable); the lever for small frames is fewer, fused kernels.
+bound on the device - by the critical path of ~500 dependent kernels that each fill a quarter of the CUs (DESIGN.md section
+5) - so a replay cannot shorten it; what it saves is the host thread (one call per pass instead of ~700 ctypes calls).
+It is therefore OFF by default (``net.use_hip_graphs = True`` or ``NVQ_GRAPH=1`` to enable).
 
 Rules (checked, never assumed):
   * parameters and buffers are baked into the graphs by address: an entry is re-captured when any address changes

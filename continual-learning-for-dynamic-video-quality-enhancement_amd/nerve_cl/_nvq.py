@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
+    "nvq_conv_pack_batch": (ci, [vp, ci, ci, vp]),
     "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp, ci, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
     "nvq_dwconv_forward": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
@@ -292,6 +293,36 @@ def pad4(c: int) -> int:
 
 
 # ----------------------------------------------------------------------------- convolution
+class PackJob(C.Structure):
+    """nvq_pack_job"""
+    _fields_ = [("w", vp), ("cout_w", ci), ("cin_w", ci), ("ksize", ci), ("transpose", ci), ("cin_store", ci),
+                ("cout_keep", ci), ("wpack", vp)]
+
+
+def conv_pack_many(reqs, math: int = MATH_F32) -> "list[torch.Tensor]":
+    """conv_pack of every (w, transpose, cin_store, cout_keep) of `reqs` in one launch per 48 jobs (nvq_conv_pack_batch);
+    the results are slices of one buffer."""
+    if not reqs:
+        return []
+    sizes, ws = [], []
+    for w, transpose, cin_store, cout_keep in reqs:
+        cout_w, cin_w, k, _ = w.shape
+        keep = (cin_w if cout_keep is None else cout_keep) if transpose else cout_w
+        sizes.append((int(lib().nvq_conv_pack_floats(keep, cin_store, k, math)), keep))
+        ws.append(w.contiguous())
+    flat = torch.empty(sum((n + 3) // 4 * 4 for n, _ in sizes), dtype=torch.float32, device=ws[0].device)
+    jobs = (PackJob * len(reqs))()
+    outs, off = [], 0
+    for i, ((w, transpose, cin_store, _), (n, keep)) in enumerate(zip(reqs, sizes)):
+        out = flat[off:off + n]
+        off += (n + 3) // 4 * 4
+        cout_w, cin_w, k, _ = w.shape
+        jobs[i] = PackJob(ptr(ws[i]), cout_w, cin_w, k, int(transpose), cin_store, keep if transpose else 0, ptr(out))
+        outs.append(out)
+    check(lib().nvq_conv_pack_batch(C.cast(jobs, vp), len(reqs), math, stream()), "nvq_conv_pack_batch")
+    return outs
+
+
 def conv_pack(w: torch.Tensor, transpose: bool, cin_store: int, cout_keep: Optional[int] = None,
               math: int = MATH_F32) -> torch.Tensor:
     """Pack a PyTorch conv weight [Cout, Cin, k, k] for nvq_conv_forward (mode-specific layout)."""

@@ -64,6 +64,13 @@ size_t nvq_conv_pack_floats(int cout, int cin_store, int ksize, int math);
 int nvq_conv_pack(const float* w, int cout_w, int cin_w, int ksize, int transpose,
                   int cin_store, int cout_keep, int math, float* wpack, void* stream);
 
+/* Several nvq_conv_pack calls in one launch: a training step packs ~120 weights, and at small frame sizes every launch costs
+ * ~18 us of device-side latency whatever its size.  Fields as the arguments of nvq_conv_pack; `jobs` is a host array. */
+typedef struct nvq_pack_job {
+    const float* w; int cout_w; int cin_w; int ksize; int transpose; int cin_store; int cout_keep; float* wpack;
+} nvq_pack_job;
+int nvq_conv_pack_batch(const nvq_pack_job* jobs, int njobs, int math, void* stream);
+
 typedef struct nvq_conv_desc {
     const float* in;  int in_ld;  int in_coff;  int cin;       /* cin % 4 == 0 stored channels */
     const float* wpack;                                          /* from nvq_conv_pack */

@@ -721,6 +721,24 @@ def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
     assert rel(from_nhwc(out), refm) < TOL
 
 
+@pytest.mark.parametrize("math_name", ["MATH_F32", "MATH_BF16"])
+def test_conv_pack_batch_equals_single_packs(K, math_name):
+    """nvq_conv_pack_batch: forward and transposed packs, 1x1 and 3x3, all three cout tile widths, more jobs than one launch
+    holds (48) - bit-identical to nvq_conv_pack, job by job."""
+    math = getattr(K, math_name)
+    shapes = [(32, 96, 3, False, 96, None), (64, 224, 1, False, 224, None), (12, 64, 3, True, 12, 64), (64, 64, 3, True, 64, 64),
+              (2, 32, 3, False, 32, None), (128, 81, 3, True, 128, 81), (3, 64, 3, True, 4, 64), (64, 192, 3, True, 64, 192)]
+    reqs = []
+    for rep in range(7):                                    # 56 jobs
+        for i, (co, ci_, k, tr, cs, keep) in enumerate(shapes):
+            reqs.append((rnd(co, ci_, k, k, seed=10 * rep + i).cuda(), tr, cs, keep))
+    many = K.conv_pack_many(reqs, math)
+    assert len(many) == len(reqs)
+    for (w, tr, cs, keep), got in zip(reqs, many):
+        assert torch.equal(got, K.conv_pack(w, tr, cs, keep, math=math))
+    assert K.conv_pack_many([], math) == []
+
+
 @pytest.mark.parametrize("cin,cout,ctr,in16,H,W", [(96, 32, 64, True, 35, 41), (64, 32, 64, True, 20, 33), (224, 64, 64, True, 19, 40),
                                                     (128, 32, 32, False, 12, 37), (96, 16, 64, True, 9, 30)])
 def test_conv_bf16_center_cin_hint(K, cin, cout, ctr, in16, H, W):

@@ -356,3 +356,4 @@ def test_lightweight_bf16_mode_runs_close_to_fp32(SR):
     assert 10 * np.log10(1.0 / max(mse, 1e-12)) > 40.0
     cos = F.cosine_similarity(grads[0], grads[1], dim=0).item()
     assert cos > 0.99, cos
+
