@@ -816,13 +816,20 @@ int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int t
         if (nsplit > ntiles) nsplit = ntiles;
         if (nsplit >= 8) nsplit &= ~7;      // multiple of the XCD count: see xcd_tile()
     }
+    NVQ_REQUIRE((size_t)nsplit * nci * nco * d.ksize * d.ksize <= (size_t)WGRAD_MAX_SLABS * 9,
+                "conv_wgrad(bf16): %d splits x %d x %d chunks exceed the workspace", nsplit, nci, nco);
     // 1x1, bf16 x and dy, >= 64 output channels: one workgroup takes 64 co (x fetched once per 64 co instead of per 32)
     if (wide && d.ksize == 1 && d.cout >= 64) {
         const int nco64 = (nco + 1) / 2;
         nsplit = WGRAD_MAX_WG / (ncig * nco64);
+        // the partial slabs (one per split x 32-ci chunk x 32-co chunk, taps * 32 * 32 floats each) must fit the workspace
+        const int cap = WGRAD_MAX_SLABS * 9 / (nci * nco * d.ksize * d.ksize);
+        if (nsplit > cap) nsplit = cap;
         if (nsplit < 1) nsplit = 1;
         if (nsplit > ntiles) nsplit = ntiles;
         if (nsplit >= 8) nsplit &= ~7;
+        NVQ_REQUIRE((size_t)nsplit * nci * nco * d.ksize * d.ksize <= (size_t)WGRAD_MAX_SLABS * 9,
+                    "conv_wgrad(bf16, 64 co): %d splits x %d x %d chunks exceed the workspace", nsplit, nci, nco);
         hipLaunchKernelGGL((wgrad_bf16_kernel<1, true, true, 64, 64>), dim3(nsplit, ncig, nco64), dim3(256), 0, s, d, tilesX,
                            tilesY, ntiles, nci, nco);
         return nsplit;

@@ -592,6 +592,7 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     int rc;
     if (d.math == NVQ_MATH_BF16) {
         const int used = conv_wgrad_bf16(d, nsplit, nci, nco, tilesX, tilesY, ntiles, s);
+        if (used < 0) return used;       // refused before any launch (message set)
         rc = check_launch("conv_wgrad_bf16");
         if (used > 0) nsplit = used;     // 64-ci workgroups use a different pixel split
     } else {
