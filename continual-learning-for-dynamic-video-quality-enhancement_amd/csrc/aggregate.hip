@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ logits, int logits_ld, int T,
                                                        int C, long HW, float* __restrict__ attn, int attn_ld,
                                                        float* __restrict__ weighted, int weighted_ld,
-                                                       float* __restrict__ gap_partial) {
+                                                       float* __restrict__ gap_partial, int aligned_bf16) {
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
     const int npl = 256 / C4;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__
         for (int t = 0; t < NVQ_MAX_T; ++t) {
             if (t < T) {
                 const float a = lg[t] * inv;
-                const float4 v = ld4(aligned + pix * aligned_ld + t * C + 4 * c4);
+                const float4 v = ldx4(aligned, (size_t)pix * aligned_ld + t * C + 4 * c4, aligned_bf16);
                 o.x += v.x * a; o.y += v.y * a; o.z += v.z * a; o.w += v.w * a;
                 if (c4 == 0) attn[pix * attn_ld + t] = a;
             }
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ aligned, int aligned_ld,
                                                        const float* __restrict__ attn, int attn_ld, int T, int C,
                                                        long HW, float* __restrict__ daligned, int daligned_ld,
-                                                       float* __restrict__ dlogits, int dlogits_ld, long total) {
+                                                       float* __restrict__ dlogits, int dlogits_ld, long total,
+                                                       int aligned_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
         a[t] = 0.f; dot[t] = 0.f;
         if (t < T) {
             a[t] = attn[pix * attn_ld + t];
-            const float4 v = ld4(aligned + pix * aligned_ld + t * C + 4 * c4);
+            const float4 v = ldx4(aligned, (size_t)pix * aligned_ld + t * C + 4 * c4, aligned_bf16);
             st4(daligned + pix * daligned_ld + t * C + 4 * c4,
                 make_float4(dw.x * a[t], dw.y * a[t], dw.z * a[t], dw.w * a[t]));
             dot[t] = group_sum(dw.x * v.x + dw.y * v.y + dw.z * v.z + dw.w * v.w, C4);
@@ -419,26 +420,26 @@ int nvq_tsum_blocks(int H, int W) { return tsum_blocks_host(H, W); }
 
 int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, int logits_ld, int T, int C,
                      int N, int H, int W, float* attn, int attn_ld, float* weighted, int weighted_ld,
-                     float* gap_partial, void* stream) {
+                     float* gap_partial, int aligned_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "tsum_forward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && logits_ld >= T && attn_ld >= T, "tsum_forward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && weighted_ld % 4 == 0 && aligned_ld >= T * C, "tsum_forward: ld");
     const dim3 grid(tsum_blocks_host(H, W), N);
     hipLaunchKernelGGL(tsum_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, aligned, aligned_ld, logits, logits_ld,
-                       T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, gap_partial);
+                       T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, gap_partial, aligned_bf16);
     return check_launch("tsum_forward");
 }
 
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix, const float* aligned,
                       int aligned_ld, const float* attn, int attn_ld, int T, int C, int N, int H, int W,
-                      float* daligned, int daligned_ld, float* dlogits, int dlogits_ld, void* stream) {
+                      float* daligned, int daligned_ld, float* dlogits, int dlogits_ld, int aligned_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "tsum_backward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && dlogits_ld >= T && attn_ld >= T, "tsum_backward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && dweighted_ld % 4 == 0 && daligned_ld % 4 == 0, "tsum_backward: ld");
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(tsum_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dweighted,
                        dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, daligned,
-                       daligned_ld, dlogits, dlogits_ld, total);
+                       daligned_ld, dlogits, dlogits_ld, total, aligned_bf16);
     return check_launch("tsum_backward");
 }
 

@@ -43,11 +43,32 @@ __device__ __forceinline__ m_u32x4 cvt_f8_bf16(float4 a, float4 b) {
 // overlaps their phases).
 template <int C, int YS>
 __device__ __forceinline__ void m_stage_halo(const float* __restrict__ src, int ld, int n, int H, int W, int ty0, int tx0,
-                                             __bf16* ys) {
+                                             __bf16* ys, int src_bf16) {
     constexpr int PPP = C / 8;                   // 16-byte bf16 pieces per pixel
     constexpr int ITEMS = MHP * PPP;
     constexpr int PER = ITEMS / M_T;             // exact: 384 * {4, 8} / 512
     static_assert(ITEMS % M_T == 0, "halo pieces must divide evenly");
+    if (src_bf16) {                              // (uniform) bf16-stored source: the pieces are copied as they are
+        const __bf16* s16 = reinterpret_cast<const __bf16*>(src);
+        m_u32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int item = threadIdx.x + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hy = hp / MHW, hx = hp - hy * MHW;
+            const int gy = ty0 + hy - MD, gx = tx0 + hx - MD;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[k] = *reinterpret_cast<const m_u32x4*>(s16 + (ok ? ((size_t)(n * H + gy) * W + gx) * ld + 8 * q : 0));
+            if (!ok) v[k] = (m_u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int item = threadIdx.x + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = v[k];
+        }
+        return;
+    }
     float4 a[PER], b[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {              // loads first (clamped addresses), conversion + stores after
@@ -75,7 +96,7 @@ template <int C, bool OUT_BF16>
 __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restrict__ x1, int x1_ld,
                                                             const float* __restrict__ x2, int x2_ld, int x2_images, int H,
                                                             int W, int tilesX, int tilesY, float* __restrict__ out,
-                                                            int out_ld) {
+                                                            int out_ld, int in_bf16) {
     constexpr int YS = OUT_BF16 ? C + 8 : C + 16;
     constexpr int KS = C / 32;                   // MFMA k-steps
     typedef typename std::conditional<OUT_BF16, __bf16, float>::type stage_t;   // staged in the output's type
@@ -93,15 +114,21 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
     // this lane's x1 operand: pixel p of row r, channels 32s + 8g .. +7   (B: k = channel, n = pixel)
     bf16x8 xb[KS];
     {
-        const float* src = x1 + (inside ? ((size_t)(n * H + gy) * W + gx) * x1_ld : 0);
+        const size_t off = inside ? ((size_t)(n * H + gy) * W + gx) * x1_ld : 0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float4 a = ld4(src + 32 * s + 8 * g), b = ld4(src + 32 * s + 8 * g + 4);
-            if (!inside) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
-            xb[s] = __builtin_bit_cast(bf16x8, cvt_f8_bf16(a, b));
+            if (in_bf16) {                                    // (uniform)
+                m_u32x4 v = *reinterpret_cast<const m_u32x4*>(reinterpret_cast<const __bf16*>(x1) + off + 32 * s + 8 * g);
+                if (!inside) v = (m_u32x4){0u, 0u, 0u, 0u};
+                xb[s] = __builtin_bit_cast(bf16x8, v);
+            } else {
+                float4 a = ld4(x1 + off + 32 * s + 8 * g), b = ld4(x1 + off + 32 * s + 8 * g + 4);
+                if (!inside) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+                xb[s] = __builtin_bit_cast(bf16x8, cvt_f8_bf16(a, b));
+            }
         }
     }
-    m_stage_halo<C, YS>(x2, x2_ld, n % x2_images, H, W, ty * MT_H, tx * MT_W, ys);
+    m_stage_halo<C, YS>(x2, x2_ld, n % x2_images, H, W, ty * MT_H, tx * MT_W, ys, in_bf16);
     stage_t* srow = stage + (r * MT_W) * M_OSTR;
     if (lane < 16) { srow[lane * M_OSTR + 81] = (stage_t)0.f; srow[lane * M_OSTR + 82] = (stage_t)0.f; srow[lane * M_OSTR + 83] = (stage_t)0.f; }
     __syncthreads();
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
                                                             const float* __restrict__ other, int other_ld,
                                                             int other_images, int H, int W, int tilesX, int tilesY,
                                                             float* __restrict__ dx, int dx_ld, int dx_coff,
-                                                            int accumulate) {
+                                                            int accumulate, int other_bf16) {
     constexpr int YS = WHICH == 1 ? C + 8 : C + 16;
     constexpr int NCB = C / 16;
     constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
@@ -206,7 +233,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
             *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = v;
         }
     }
-    m_stage_halo<C, YS>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys);
+    m_stage_halo<C, YS>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys, other_bf16);
     __syncthreads();
 
     f32x4 acc[NCB];
@@ -268,12 +295,13 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
 bool corr_mfma_supported(int C) { return C == 32 || C == 64; }
 
 int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C, int N, int H, int W,
-                      float* out, int out_ld, int out_bf16, hipStream_t s) {
+                      float* out, int out_ld, int out_bf16, int in_bf16, hipStream_t s) {
+    NVQ_REQUIRE(!in_bf16 || (x1_ld % 8 == 0 && x2_ld % 8 == 0), "correlation_forward(bf16): bf16 inputs need ld %% 8 == 0");
     NVQ_REQUIRE(out_ld >= 84 && out_ld % (out_bf16 ? 8 : 4) == 0, "correlation_forward(bf16): out_ld %d", out_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CF(CC, OB) \
-    hipLaunchKernelGGL((corr_fwd_mfma_kernel<CC, OB>), grid, dim3(M_T), 0, s, x1, x1_ld, x2, x2_ld, x2_images, H, W, tilesX, tilesY, out, out_ld)
+    hipLaunchKernelGGL((corr_fwd_mfma_kernel<CC, OB>), grid, dim3(M_T), 0, s, x1, x1_ld, x2, x2_ld, x2_images, H, W, tilesX, tilesY, out, out_ld, in_bf16)
     if (C == 64) { if (out_bf16) NVQ_CF(64, true); else NVQ_CF(64, false); }
     else { if (out_bf16) NVQ_CF(32, true); else NVQ_CF(32, false); }
 #undef NVQ_CF
@@ -282,13 +310,14 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
 
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       hipStream_t s) {
+                       int other_bf16, hipStream_t s) {
+    NVQ_REQUIRE(!other_bf16 || other_ld % 8 == 0, "correlation_backward(bf16): a bf16 `other` needs ld %% 8 == 0");
     NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
                 "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \
-    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate)
+    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16)
 #define NVQ_CB2(CC) \
     do { if (which == 1) { if (dcorr_bf16) NVQ_CB(CC, 1, true); else NVQ_CB(CC, 1, false); } \
          else { if (dcorr_bf16) NVQ_CB(CC, 2, true); else NVQ_CB(CC, 2, false); } } while (0)

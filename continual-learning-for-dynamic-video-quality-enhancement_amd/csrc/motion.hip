@@ -243,7 +243,7 @@ __device__ __forceinline__ WarpGeom warp_geom(float fx, float fy, int x, int y, 
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ feat, int feat_ld,
                                                        const float* __restrict__ flow, int flow_ld, int C,
                                                        int H, int W, float* __restrict__ out, int out_ld,
-                                                       int out_coff, long total) {
+                                                       int out_coff, long total, int feat_bf16, int out_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -254,16 +254,15 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     const long img = pix - ((long)y * W + x);  // first pixel of this image
     const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* base = feat + 4 * c4;
-    if (g.vnw) { const float4 v = ld4(base + (img + (long)g.y0 * W + g.x0) * feat_ld);
+    if (g.vnw) { const float4 v = ldx4(feat, (size_t)(img + (long)g.y0 * W + g.x0) * feat_ld + 4 * c4, feat_bf16);
         acc.x += v.x * g.wnw; acc.y += v.y * g.wnw; acc.z += v.z * g.wnw; acc.w += v.w * g.wnw; }
-    if (g.vne) { const float4 v = ld4(base + (img + (long)g.y0 * W + g.x0 + 1) * feat_ld);
+    if (g.vne) { const float4 v = ldx4(feat, (size_t)(img + (long)g.y0 * W + g.x0 + 1) * feat_ld + 4 * c4, feat_bf16);
         acc.x += v.x * g.wne; acc.y += v.y * g.wne; acc.z += v.z * g.wne; acc.w += v.w * g.wne; }
-    if (g.vsw) { const float4 v = ld4(base + (img + (long)(g.y0 + 1) * W + g.x0) * feat_ld);
+    if (g.vsw) { const float4 v = ldx4(feat, (size_t)(img + (long)(g.y0 + 1) * W + g.x0) * feat_ld + 4 * c4, feat_bf16);
         acc.x += v.x * g.wsw; acc.y += v.y * g.wsw; acc.z += v.z * g.wsw; acc.w += v.w * g.wsw; }
-    if (g.vse) { const float4 v = ld4(base + (img + (long)(g.y0 + 1) * W + g.x0 + 1) * feat_ld);
+    if (g.vse) { const float4 v = ldx4(feat, (size_t)(img + (long)(g.y0 + 1) * W + g.x0 + 1) * feat_ld + 4 * c4, feat_bf16);
         acc.x += v.x * g.wse; acc.y += v.y * g.wse; acc.z += v.z * g.wse; acc.w += v.w * g.wse; }
-    st4(out + pix * out_ld + out_coff + 4 * c4, acc);
+    stx4(out, (size_t)pix * out_ld + out_coff + 4 * c4, out_bf16, acc);
 }
 
 // One thread per (pixel, channel): the lanes of a pixel issue their float atomics on C consecutive floats
@@ -337,7 +336,8 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
                                                            const float* __restrict__ flow, int flow_ld, int C, int H, int W,
                                                            float* __restrict__ dfeat, int dfeat_ld,
                                                            float* __restrict__ dflow, int dflow_ld,
-                                                           float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix) {
+                                                           float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix,
+                                                           int feat_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     const long pix = gid >> 4;
     if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
         const float4 go = ld4(dout + pix * dout_ld + dout_coff + ch);
         auto corner = [&](bool valid, long o, float wgt, float sx, float sy) {
             if (!valid) return;
-            const float4 f = ld4(feat + o * feat_ld + ch);
+            const float4 f = ldx4(feat, (size_t)o * feat_ld + ch, feat_bf16);
             const float dsum = f.x * go.x + f.y * go.y + f.z * go.z + f.w * go.w;
             gix += sx * dsum;
             giy += sy * dsum;
@@ -472,10 +472,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
 // NVQ_MATH_BF16 variants (corr_mfma.hip)
 bool corr_mfma_supported(int C);
 int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C, int N, int H, int W,
-                      float* out, int out_ld, int out_bf16, hipStream_t s);
+                      float* out, int out_ld, int out_bf16, int in_bf16, hipStream_t s);
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       hipStream_t s);
+                       int other_bf16, hipStream_t s);
 
 }  // namespace nvq
 
@@ -484,14 +484,16 @@ using namespace nvq;
 extern "C" {
 
 int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld, int x2_images, int C,
-                            int N, int H, int W, float* out, int out_ld, int math, int out_bf16, void* stream) {
+                            int N, int H, int W, float* out, int out_ld, int math, int out_bf16, int in_bf16,
+                            void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x1_ld % 4 == 0 && x2_ld % 4 == 0 && out_ld % 4 == 0 && out_ld >= 84 &&
                     aligned16(x1) && aligned16(x2) && aligned16(out),
                 "correlation_forward: alignment (C %d out_ld %d)", C, out_ld);
     NVQ_REQUIRE(x2_images > 0, "correlation_forward: x2_images");
     if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
-        return corr_forward_mfma(x1, x1_ld, x2, x2_ld, x2_images, C, N, H, W, out, out_ld, out_bf16, (hipStream_t)stream);
-    NVQ_REQUIRE(!out_bf16, "correlation_forward: bf16 output needs NVQ_MATH_BF16 and C in {32, 64}");
+        return corr_forward_mfma(x1, x1_ld, x2, x2_ld, x2_images, C, N, H, W, out, out_ld, out_bf16, in_bf16,
+                                 (hipStream_t)stream);
+    NVQ_REQUIRE(!out_bf16 && !in_bf16, "correlation_forward: bf16 tensors need NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     hipLaunchKernelGGL(corr_fwd_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, (hipStream_t)stream,
                        x1, x1_ld, x2, x2_ld, x2_images, C, H, W, tilesX, tilesY, out, out_ld);
@@ -500,7 +502,7 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
 
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const float* other, int other_ld,
                              int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff,
-                             int accumulate, int math, int dcorr_bf16, void* stream) {
+                             int accumulate, int math, int dcorr_bf16, int other_bf16, void* stream) {
     NVQ_REQUIRE(which == 1 || which == 2, "correlation_backward: which %d", which);
     NVQ_REQUIRE(C % 4 == 0 && dcorr_ld % 4 == 0 && dcorr_ld >= 84 && other_ld % 4 == 0 && dx_ld % 4 == 0 &&
                     dx_coff % 4 == 0 && aligned16(dcorr) && aligned16(other) && aligned16(dx),
@@ -508,8 +510,8 @@ int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const 
     NVQ_REQUIRE(other_images > 0, "correlation_backward: other_images");
     if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
         return corr_backward_mfma(which, dcorr, dcorr_ld, dcorr_bf16, other, other_ld, other_images, C, N, H, W, dx, dx_ld,
-                                  dx_coff, accumulate, (hipStream_t)stream);
-    NVQ_REQUIRE(!dcorr_bf16, "correlation_backward: bf16 dcorr needs NVQ_MATH_BF16 and C in {32, 64}");
+                                  dx_coff, accumulate, other_bf16, (hipStream_t)stream);
+    NVQ_REQUIRE(!dcorr_bf16 && !other_bf16, "correlation_backward: bf16 tensors need NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
     if (which == 1)
@@ -522,20 +524,21 @@ int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const 
 }
 
 int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
-                     float* out, int out_ld, int out_coff, void* stream) {
+                     float* out, int out_ld, int out_coff, int feat_bf16, int out_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && feat_ld % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0 && flow_ld >= 2 &&
                     aligned16(feat) && aligned16(out),
                 "warp_forward: alignment");
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, feat_ld,
-                       flow, flow_ld, C, H, W, out, out_ld, out_coff, total);
+                       flow, flow_ld, C, H, W, out, out_ld, out_coff, total, feat_bf16, out_bf16);
     return check_launch("warp_forward");
 }
 
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
-                      float* dflow, int dflow_ld, float* records, size_t records_bytes, void* stream) {
+                      float* dflow, int dflow_ld, float* records, size_t records_bytes, int feat_bf16, void* stream) {
     NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
+    NVQ_REQUIRE(!feat_bf16 || records, "warp_backward: bf16-stored features need the gather form (records != NULL)");
     NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
     if (records) {                                            // gather form (deterministic, no atomics for |flow| < 4 px)
         const long npix = (long)N * H * W;
@@ -547,7 +550,7 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
         int* rec_code = reinterpret_cast<int*>(rec_w + npix);
         hipStream_t s = (hipStream_t)stream;
         hipLaunchKernelGGL(warp_bwd_src_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, feat,
-                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix);
+                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16);
         int rc = check_launch("warp_backward(src)");
         if (rc) return rc;
         const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;

@@ -12,6 +12,7 @@ block owns one [B,H,W,F+160] buffer, layer i reads channels [0, F+32i) and write
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -135,8 +136,13 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
 
     # ---- feature extractor, all T frames in one batch (slot order)
-    aligned = _new(dev, B, H, W, T * F)
-    feat_oth = _new(dev, max(NO, 1), H, W, F)
+    # bf16 activation mode: the frames' features (`aligned`: centre frame + warped neighbours, `feat_oth`: the neighbours
+    # before warping) are stored as bf16 like every other conv-internal tensor; their non-conv readers (correlation on
+    # the matrix cores, warp, softmax-weighted sum) take a storage flag.  NVQ_BF16_FEATURES=0 keeps them fp32.
+    feat_dtype = act_dtype if (act_dtype == torch.bfloat16 and math == K.MATH_BF16 and F in (32, 64)
+                               and os.environ.get("NVQ_BF16_FEATURES", "1") != "0") else torch.float32
+    aligned = _new(dev, B, H, W, T * F, dtype=feat_dtype)
+    feat_oth = _new(dev, max(NO, 1), H, W, F, dtype=feat_dtype)
     sv.aligned, sv.feat_oth = aligned, feat_oth
     if features is None:
         _extract(P, frames, g.slots, F, training, math, act_dtype, Sl(aligned, F, c * F), B, Sl(feat_oth) if NO else None, sv)

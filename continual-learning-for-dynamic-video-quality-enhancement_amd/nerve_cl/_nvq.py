@@ -91,13 +91,13 @@ SIGNATURES = {
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
-    "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
-    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
-    "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, vp]),
-    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, vp]),
+    "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
-    "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp]),
-    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
+    "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
+    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]),
     "nvq_cbam_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp]),
@@ -548,22 +548,25 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
 
 # ----------------------------------------------------------------------------- motion
 def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor, math: int = MATH_F32):
+    """x1 / x2: fp32, or (MATH_BF16, C in {32, 64}) both bf16-stored feature tensors."""
     N, H, W, _ = x1.t.shape
+    assert x1.bf16 == x2.bf16
     check(lib().nvq_correlation_forward(x1.base(), x1.ld, x2.base(), x2.ld, x2.n, x1.c, N, H, W, ptr(out),
-                                        out.shape[-1], math, is_bf16(out), stream()), "nvq_correlation_forward")
+                                        out.shape[-1], math, is_bf16(out), x1.bf16, stream()), "nvq_correlation_forward")
 
 
 def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32):
     N, H, W, ld = dcorr.shape
     check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N, H, W,
-                                         ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), stream()),
+                                         ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), other.bf16,
+                                         stream()),
           "nvq_correlation_backward")
 
 
 def warp_forward(feat: Sl, flow: torch.Tensor, out: Sl):
     N, H, W, _ = feat.t.shape
     check(lib().nvq_warp_forward(feat.base(), feat.ld, ptr(flow), flow.shape[-1], feat.c, N, H, W, ptr(out.t),
-                                 out.ld, out.coff, stream()), "nvq_warp_forward")
+                                 out.ld, out.coff, feat.bf16, out.bf16, stream()), "nvq_warp_forward")
 
 
 def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torch.Tensor, gather: bool = True):
@@ -572,7 +575,7 @@ def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torc
     rec = torch.empty(N * H * W * 5, dtype=torch.float32, device=flow.device) if gather else None
     check(lib().nvq_warp_backward(ptr(dout.t), dout.ld, dout.coff, feat.base(), feat.ld, ptr(flow),
                                   flow.shape[-1], feat.c, N, H, W, dfeat.base(), dfeat.ld, ptr(dflow),
-                                  dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, stream()),
+                                  dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, feat.bf16, stream()),
           "nvq_warp_backward")
 
 
@@ -584,7 +587,8 @@ def tsum_blocks(H: int, W: int) -> int:
 def tsum_forward(aligned: torch.Tensor, logits: torch.Tensor, T: int, Cc: int, attn, weighted, gap_partial):
     N, H, W, ld = aligned.shape
     check(lib().nvq_tsum_forward(ptr(aligned), ld, ptr(logits), logits.shape[-1], T, Cc, N, H, W, ptr(attn),
-                                 attn.shape[-1], ptr(weighted), weighted.shape[-1], ptr(gap_partial), stream()),
+                                 attn.shape[-1], ptr(weighted), weighted.shape[-1], ptr(gap_partial), is_bf16(aligned),
+                                 stream()),
           "nvq_tsum_forward")
 
 
@@ -592,7 +596,7 @@ def tsum_backward(dweighted, dgap_pix, aligned, attn, T: int, Cc: int, daligned,
     N, H, W, ld = aligned.shape
     check(lib().nvq_tsum_backward(ptr(dweighted), dweighted.shape[-1], ptr(dgap_pix), ptr(aligned), ld, ptr(attn),
                                   attn.shape[-1], T, Cc, N, H, W, ptr(daligned), daligned.shape[-1], ptr(dlogits),
-                                  dlogits.shape[-1], stream()), "nvq_tsum_backward")
+                                  dlogits.shape[-1], is_bf16(aligned), stream()), "nvq_tsum_backward")
 
 
 def cbam_channel(gap_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca):

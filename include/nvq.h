@@ -230,36 +230,39 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
  * of each pixel are written as zero.  x2 image index = n % x2_images (centre-frame
  * features are shared by the T-1 reference frames).
  * math == NVQ_MATH_BF16 (and C in {32, 64}): the products run on the bf16 matrix cores (x1 / x2 rounded to bf16,
- * fp32 accumulation) and out may be stored as bf16 (out_bf16; out_ld then a multiple of 8).  Otherwise exact fp32. */
+ * fp32 accumulation), out may be stored as bf16 (out_bf16; out_ld then a multiple of 8) and x1 / x2 may be bf16-stored
+ * feature tensors (in_bf16, both; their ld then count bf16 elements and are multiples of 8).  Otherwise exact fp32. */
 int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_ld,
                             int x2_images, int C, int N, int H, int W,
-                            float* out, int out_ld, int math, int out_bf16, void* stream);
+                            float* out, int out_ld, int math, int out_bf16, int in_bf16, void* stream);
 /* which == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d] * other[n % other_images, p+off(d), c]
  *             (gradient w.r.t. x1; other = x2)
  * which == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n, q-off(d), c]
  *             (gradient w.r.t. x2 contributed by image n; other = x1, other_images = N;
  *              the caller launches once per reference frame so that the sums into the
  *              shared centre-frame gradient are ordered)
- * math / dcorr_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96). */
+ * math / dcorr_bf16 / other_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96).  dx is fp32. */
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
                              const float* other, int other_ld, int other_images, int C, int N,
                              int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                             int math, int dcorr_bf16, void* stream);
+                             int math, int dcorr_bf16, int other_bf16, void* stream);
 
 /* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
- * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2]. */
+ * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2] fp32.
+ * feat_bf16 / out_bf16: storage type of the two feature tensors (fp32 interpolation arithmetic either way). */
 int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow_ld,
                      int C, int N, int H, int W, float* out, int out_ld, int out_coff,
-                     void* stream);
+                     int feat_bf16, int out_bf16, void* stream);
 /* dfeat must be pre-initialised (the gradient is ADDED to it); dflow [N,H,W,dflow_ld] gets channels 0,1 written and
  * 2..dflow_ld-1 zeroed.  records == NULL: scatter form, 4 float atomics per (pixel, channel).  records != NULL (20 bytes
  * per pixel of scratch, 16-byte aligned): gather form - a per-source pass writes the flow gradient and a {corner offset,
  * 4 weights} record, a per-destination pass collects the contributions from the 9x9 window around each pixel; no atomics
- * and a fixed summation order for every source whose flow is shorter than 4 pixels (longer ones are still scattered). */
+ * and a fixed summation order for every source whose flow is shorter than 4 pixels (longer ones are still scattered).
+ * feat_bf16: `feat` (read for the flow gradient) is stored as bf16 - gather form only; dout, dfeat, dflow are fp32. */
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat,
                       int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
                       float* dfeat, int dfeat_ld, float* dflow, int dflow_ld,
-                      float* records, size_t records_bytes, void* stream);
+                      float* records, size_t records_bytes, int feat_bf16, void* stream);
 
 /* ------------------------------------------------------------------ temporal aggregation
  * TemporalAggregator.forward softmax + weighted sum, super_resolution.py:174,203-204:
@@ -269,13 +272,14 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
 int nvq_tsum_blocks(int H, int W);
 int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, int logits_ld,
                      int T, int C, int N, int H, int W, float* attn, int attn_ld,
-                     float* weighted, int weighted_ld, float* gap_partial, void* stream);
+                     float* weighted, int weighted_ld, float* gap_partial, int aligned_bf16, void* stream);
+/* aligned_bf16 (here and below): `aligned` is stored as bf16 (aligned_ld counts bf16 elements); everything else is fp32. */
 /* dw = dweighted + dgap_pix[n][c] (dgap_pix may be NULL);
  * daligned[n,p,t*C+c] = dw*attn_t ; dlogits = softmax backward of sum_c dw*aligned_t. */
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix,
                       const float* aligned, int aligned_ld, const float* attn, int attn_ld,
                       int T, int C, int N, int H, int W, float* daligned, int daligned_ld,
-                      float* dlogits, int dlogits_ld, void* stream);
+                      float* dlogits, int dlogits_ld, int aligned_bf16, void* stream);
 
 /* CBAM, efficient_layers.py:154-228.
  * cbam_channel: gap = mean(weighted); hid = relu(W1 gap); ca = sigmoid(W2 hid).

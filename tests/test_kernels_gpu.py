@@ -698,6 +698,66 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
     assert rel(from_nhwc(dx2), x2.grad) < TOL
 
 
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 19, 37), (32, 1, 9, 20)])
+def test_bf16_stored_feature_tensors(K, C, B, H, W):
+    """The storage flags of the non-conv readers of the feature tensors (correlation on the matrix cores, warp, softmax-
+    weighted sum): with bf16-stored inputs every kernel returns exactly what it returns for fp32 tensors holding the same
+    (bf16-representable) values - the flag changes how a value is loaded, nothing else."""
+    T, R = 3, 2
+    N = B * R
+    feat = bf(rnd(N, C, H, W))                               # neighbours' features
+    al = bf(rnd(B, T * C, H, W, seed=2))                     # aligned: [centre | warped neighbours]
+    f32, a32 = to_nhwc(feat), to_nhwc(al)
+    f16, a16 = f32.bfloat16(), a32.bfloat16()
+    assert torch.equal(f16.float(), f32) and torch.equal(a16.float(), a32)
+    # correlation forward / both gradients
+    outs = []
+    for fb, ab in ((f32, a32), (f16, a16)):
+        corr = torch.empty(N, H, W, 128, device="cuda", dtype=torch.bfloat16)
+        K.correlation_forward(K.Sl(fb), K.Sl(ab, C, C), corr, math=K.MATH_BF16)
+        dcorr = to_nhwc(bf(rnd(N, 81, H, W, seed=5)), 128).bfloat16()
+        dx1 = torch.zeros(N, H, W, C, device="cuda")
+        K.correlation_backward(1, dcorr, K.Sl(ab, C, C), K.Sl(dx1), False, math=K.MATH_BF16)
+        dx2 = torch.zeros(B, H, W, C, device="cuda")
+        for r in range(R):
+            K.correlation_backward(2, dcorr[r * B:(r + 1) * B], K.Sl(fb).images(r * B, (r + 1) * B), K.Sl(dx2), True,
+                                   math=K.MATH_BF16)
+        outs.append((corr, dx1, dx2))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # warp forward (fp32 and bf16 output) and backward
+    flow = to_nhwc(rnd(B, 2, H, W, seed=7) * 1.7, 4)
+    outs = []
+    for fb, odt in ((f32, torch.float32), (f16, torch.float32), (f16, torch.bfloat16)):
+        wo = torch.zeros(B, H, W, T * C, device="cuda", dtype=odt)
+        K.warp_forward(K.Sl(fb).images(0, B), flow, K.Sl(wo, C, 2 * C))
+        dfeat, dflow = torch.zeros(B, H, W, C, device="cuda"), torch.empty(B, H, W, 4, device="cuda")
+        K.warp_backward(K.Sl(to_nhwc(rnd(B, T * C, H, W, seed=9)), C, 2 * C), K.Sl(fb).images(0, B), flow, K.Sl(dfeat), dflow)
+        outs.append((wo, dfeat, dflow))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[0][0].bfloat16())
+    for k in (1, 2):
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
+    assert outs[0][0][..., :2 * C].abs().max().item() == 0
+    with pytest.raises(RuntimeError, match="gather form"):
+        K.warp_backward(K.Sl(to_nhwc(rnd(B, T * C, H, W, seed=9)), C, 2 * C), K.Sl(f16).images(0, B), flow,
+                        K.Sl(torch.zeros(B, H, W, C, device="cuda")), torch.empty(B, H, W, 4, device="cuda"), gather=False)
+    # softmax-weighted sum forward / backward
+    lg = to_nhwc(rnd(B, T, H, W, seed=3) * 3, 4)
+    outs = []
+    for ab in (a32, a16):
+        attn, wt = torch.empty(B, H, W, 4, device="cuda"), torch.empty(B, H, W, C, device="cuda")
+        gp = torch.empty(B, K.tsum_blocks(H, W), C, device="cuda")
+        K.tsum_forward(ab, lg, T, C, attn, wt, gp)
+        dal, dlg = torch.empty(B, H, W, T * C, device="cuda"), torch.empty(B, H, W, 4, device="cuda")
+        K.tsum_backward(to_nhwc(rnd(B, C, H, W, seed=6)), (rnd(B, C, seed=8) * 0.1).cuda(), ab, attn, T, C, dal, dlg)
+        outs.append((attn, wt, gp, dal, dlg))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # exact-fp32 correlation refuses bf16-stored inputs
+    with pytest.raises(RuntimeError, match="NVQ_MATH_BF16"):
+        K.correlation_forward(K.Sl(f16), K.Sl(a16, C, C), torch.empty(N, H, W, 96, device="cuda"), math=K.MATH_F32)
+
+
 @pytest.mark.parametrize("cin,N,H,W", [(96, 2, 35, 41), (64, 1, 16, 32), (160, 3, 50, 70)])
 def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
     """The 16x32-tile 3x3 kernel (bf16 input, cout 32, H >= 16): bias + ReLU written in place into the concat buffer, and
