@@ -200,7 +200,8 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     sm, amax, sa = _new(dev, B, H, W, 2), _new(dev, B, H, W, dtype=torch.int32), _new(dev, B, H, W)
     K.cbam_pool(weighted, ca, sm, amax)
     cats = [_new(dev, B, H, W, g.CATLD, dtype=act_dtype) for _ in range(nblocks)]
-    resout = _new(dev, B, H, W, F)
+    # (with no dense blocks the CBAM kernel, an fp32 writer, fills this tensor)
+    resout = _new(dev, B, H, W, F, dtype=act_dtype if nblocks else torch.float32)
 
     def xloc(k):  # where the input of block k / the output of block k-1 lives
         return Sl(cats[k], F, 0) if k < nblocks else Sl(resout)
@@ -237,7 +238,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
     K.TIMER_TAG = ""
     # ---- global fusion + upsampler tail
-    fused, gr = _new(dev, B, H, W, F), _new(dev, B, H, W, F)
+    fused, gr = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)   # conv-to-conv tensors
     K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F, math=math), P["gff.0.bias"], Sl(fused), 3,
                    relu=True, out2=Sl(gr), res=center, math=math)
     u = _new(dev, B, H, W, g.Up)
@@ -288,7 +289,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dfeat_all = _new(dev, NI, H, W, F)              # gradient w.r.t. the features of every frame (slot order)
     dfeat_all[B:].zero_()                           # the centre frames' part is first written (out2 below), the rest added to
     dfeat_c = dfeat_all[:B]
-    dg = _new(dev, B, H, W, F)
+    dg = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
                    out2=Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
     # ---- gff
