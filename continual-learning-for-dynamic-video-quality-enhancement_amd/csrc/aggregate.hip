@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ attn, int attn_ld, int T, int C,
                                                        long HW, float* __restrict__ daligned, int daligned_ld,
                                                        float* __restrict__ dlogits, int dlogits_ld, long total,
-                                                       int aligned_bf16) {
+                                                       int aligned_bf16, int daligned_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
         if (t < T) {
             a[t] = attn[pix * attn_ld + t];
             const float4 v = ldx4(aligned, (size_t)pix * aligned_ld + t * C + 4 * c4, aligned_bf16);
-            st4(daligned + pix * daligned_ld + t * C + 4 * c4,
-                make_float4(dw.x * a[t], dw.y * a[t], dw.z * a[t], dw.w * a[t]));
+            stx4(daligned, (size_t)pix * daligned_ld + t * C + 4 * c4, daligned_bf16,
+                 make_float4(dw.x * a[t], dw.y * a[t], dw.z * a[t], dw.w * a[t]));
             dot[t] = group_sum(dw.x * v.x + dw.y * v.y + dw.z * v.z + dw.w * v.w, C4);
             sdot += a[t] * dot[t];
         }
@@ -432,14 +432,15 @@ int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, 
 
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix, const float* aligned,
                       int aligned_ld, const float* attn, int attn_ld, int T, int C, int N, int H, int W,
-                      float* daligned, int daligned_ld, float* dlogits, int dlogits_ld, int aligned_bf16, void* stream) {
+                      float* daligned, int daligned_ld, float* dlogits, int dlogits_ld, int aligned_bf16,
+                      int daligned_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "tsum_backward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && dlogits_ld >= T && attn_ld >= T, "tsum_backward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && dweighted_ld % 4 == 0 && daligned_ld % 4 == 0, "tsum_backward: ld");
     const long total = (long)N * H * W * (C / 4);
     hipLaunchKernelGGL(tsum_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dweighted,
                        dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, daligned,
-                       daligned_ld, dlogits, dlogits_ld, total, aligned_bf16);
+                       daligned_ld, dlogits, dlogits_ld, total, aligned_bf16, daligned_bf16);
     return check_launch("tsum_backward");
 }
 

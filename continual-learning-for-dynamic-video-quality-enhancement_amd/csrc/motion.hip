@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
                                                            float* __restrict__ dfeat, int dfeat_ld,
                                                            float* __restrict__ dflow, int dflow_ld,
                                                            float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix,
-                                                           int feat_bf16) {
+                                                           int feat_bf16, int dout_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     const long pix = gid >> 4;
     if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
     const bool scatter = any && !near;
     float gix = 0.f, giy = 0.f;
     for (int ch = 4 * c4; ch < C; ch += 64) {
-        const float4 go = ld4(dout + pix * dout_ld + dout_coff + ch);
+        const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
         auto corner = [&](bool valid, long o, float wgt, float sx, float sy) {
             if (!valid) return;
             const float4 f = ldx4(feat, (size_t)o * feat_ld + ch, feat_bf16);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                                                               const float4* __restrict__ rec_w,
                                                               const int* __restrict__ rec_code, int C, int H, int W,
                                                               int tilesX, int tilesY, float* __restrict__ dfeat,
-                                                              int dfeat_ld) {
+                                                              int dfeat_ld, int dout_bf16) {
     __shared__ float4 lw[WG_HH * WG_HW];
     __shared__ int lc[WG_HH * WG_HW];
     __shared__ int hit_n[WG_TH * WG_TW];
@@ -435,9 +435,12 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                         hit_w[threadIdx.x * WG_MAXHIT + cnt] = wgt;
                         ++cnt;
                     } else {                                  // overflow: apply directly (still no atomics: q is ours)
-                        const float* src = dout + ((long)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff;
+                        const size_t so = ((size_t)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff;
                         float* dst = dfeat + ((long)(n * H + qy) * W + qx) * dfeat_ld;
-                        for (int ch = 0; ch < C; ++ch) dst[ch] += wgt * src[ch];
+                        for (int ch = 0; ch < C; ch += 4) {   // C % 4 == 0
+                            const float4 v = ldx4(dout, so + ch, dout_bf16);
+                            dst[ch] += wgt * v.x; dst[ch + 1] += wgt * v.y; dst[ch + 2] += wgt * v.z; dst[ch + 3] += wgt * v.w;
+                        }
                     }
                 }
         }
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                 const int hp = hit_p[qi * WG_MAXHIT + k];
                 const float wgt = hit_w[qi * WG_MAXHIT + k];
                 const int sy = (hp >> 4) - WG_R, sx = (hp & 15) - WG_R;
-                const float4 v = ld4(dout + ((long)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff + ch);
+                const float4 v = ldx4(dout, ((size_t)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff + ch, dout_bf16);
                 acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
             }
             float* dst = dfeat + qpix * dfeat_ld + ch;
@@ -536,9 +539,10 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
-                      float* dflow, int dflow_ld, float* records, size_t records_bytes, int feat_bf16, void* stream) {
+                      float* dflow, int dflow_ld, float* records, size_t records_bytes, int feat_bf16, int dout_bf16,
+                      void* stream) {
     NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
-    NVQ_REQUIRE(!feat_bf16 || records, "warp_backward: bf16-stored features need the gather form (records != NULL)");
+    NVQ_REQUIRE(!(feat_bf16 || dout_bf16) || records, "warp_backward: bf16-stored tensors need the gather form (records != NULL)");
     NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
     if (records) {                                            // gather form (deterministic, no atomics for |flow| < 4 px)
         const long npix = (long)N * H * W;
@@ -550,12 +554,12 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
         int* rec_code = reinterpret_cast<int*>(rec_w + npix);
         hipStream_t s = (hipStream_t)stream;
         hipLaunchKernelGGL(warp_bwd_src_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, feat,
-                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16);
+                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16, dout_bf16);
         int rc = check_launch("warp_backward(src)");
         if (rc) return rc;
         const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;
         hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout, dout_ld,
-                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld);
+                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, dout_bf16);
         return check_launch("warp_backward(gather)");
     }
     const long total = (long)N * H * W * (C < 64 ? C : 64);

@@ -1034,13 +1034,13 @@ __global__ __launch_bounds__(256) void axpy_slice_kernel(float* __restrict__ dst
                                                          const float* __restrict__ src, int src_ld,
                                                          int src_coff, const float* __restrict__ mask,
                                                          int mask_ld, int mask_coff, int C, float alpha,
-                                                         int accumulate, long total) {
+                                                         int accumulate, long total, int src_bf16) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
     const int c4 = gid % C4;
     const long pix = gid / C4;
-    float4 v = ld4(src + pix * src_ld + src_coff + 4 * c4);
+    float4 v = ldx4(src, (size_t)pix * src_ld + src_coff + 4 * c4, src_bf16);
     v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
     if (mask) {
         const float4 m = ld4(mask + pix * mask_ld + mask_coff + 4 * c4);
@@ -1142,9 +1142,9 @@ int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W, con
     if ((row * (nblk + 1)) * sizeof(float) > workspace_bytes) { set_error("head_wgrad: workspace"); return NVQ_EWORKSPACE; }
     rc = launch_reduce_partials(workspace, nblk, (int)row, 1.f, scratch, 0, s);
     if (rc) return rc;
-    rc = nvq_axpy_slice(dweight, F * K, 0, scratch, F * K, 0, nullptr, 0, 0, F * K, 1, 1.f, accumulate, stream);
+    rc = nvq_axpy_slice(dweight, F * K, 0, scratch, F * K, 0, nullptr, 0, 0, F * K, 1, 1.f, accumulate, 0, stream);
     if (rc) return rc;
-    return nvq_axpy_slice(dbias, F, 0, scratch + F * K, F, 0, nullptr, 0, 0, F, 1, 1.f, accumulate, stream);
+    return nvq_axpy_slice(dbias, F, 0, scratch + F * K, F, 0, nullptr, 0, 0, F, 1, 1.f, accumulate, 0, stream);
 }
 
 static DwBn make_dwbn(const nvq_bn_input* b, int C) {
@@ -1316,14 +1316,14 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
 
 int nvq_axpy_slice(float* dst, int dst_ld, int dst_coff, const float* src, int src_ld, int src_coff,
                    const float* mask, int mask_ld, int mask_coff, int C, long npix, float alpha,
-                   int accumulate, void* stream) {
+                   int accumulate, int src_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && src_ld % 4 == 0 && src_coff % 4 == 0 &&
                     (!mask || (mask_ld % 4 == 0 && mask_coff % 4 == 0)) && aligned16(dst) && aligned16(src),
                 "axpy_slice: alignment (C %d ld %d/%d)", C, dst_ld, src_ld);
     const long total = npix * (C / 4);
     if (total == 0) return NVQ_OK;
     hipLaunchKernelGGL(axpy_slice_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld,
-                       dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total);
+                       dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total, src_bf16);
     return check_launch("axpy_slice");
 }
 

@@ -356,7 +356,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                        G["temporal_aggregator.refine.channel_attention.fc.2.weight"], dgap_pix)
 
     # ---- softmax-weighted sum and the attention convs
-    daligned = _new(dev, B, H, W, T * F)
+    daligned = _new(dev, B, H, W, T * F, dtype=sv.aligned.dtype)   # stored like `aligned` (bf16 in the bf16 activation mode)
     dlogits = _new(dev, B, H, W, g.Tp)
     K.tsum_backward(dweighted, dgap_pix, sv.aligned, sv.attn, T, F, daligned, dlogits)
     pre = "temporal_aggregator.attention."

@@ -94,10 +94,10 @@ SIGNATURES = {
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, vp]),
+    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
     "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
-    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp]),
+    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, vp]),
     "nvq_cbam_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp]),
@@ -108,7 +108,7 @@ SIGNATURES = {
     "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_clamp_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_bicubic_blend": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]),
-    "nvq_axpy_slice": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, cl, cf, ci, vp]),
+    "nvq_axpy_slice": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, cl, cf, ci, ci, vp]),
     "nvq_colsum": (ci, [vp, ci, ci, ci, cl, cf, vp, vp, sz, ci, vp]),
     "nvq_ewc_penalty": (ci, [vp, vp, vp, cl, cf, vp, vp, sz, vp]),
     "nvq_ewc_penalty_grad": (ci, [vp, vp, vp, cl, cf, vp, vp, ci, vp]),
@@ -575,7 +575,8 @@ def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torc
     rec = torch.empty(N * H * W * 5, dtype=torch.float32, device=flow.device) if gather else None
     check(lib().nvq_warp_backward(ptr(dout.t), dout.ld, dout.coff, feat.base(), feat.ld, ptr(flow),
                                   flow.shape[-1], feat.c, N, H, W, dfeat.base(), dfeat.ld, ptr(dflow),
-                                  dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, feat.bf16, stream()),
+                                  dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, feat.bf16, dout.bf16,
+                                  stream()),
           "nvq_warp_backward")
 
 
@@ -596,7 +597,7 @@ def tsum_backward(dweighted, dgap_pix, aligned, attn, T: int, Cc: int, daligned,
     N, H, W, ld = aligned.shape
     check(lib().nvq_tsum_backward(ptr(dweighted), dweighted.shape[-1], ptr(dgap_pix), ptr(aligned), ld, ptr(attn),
                                   attn.shape[-1], T, Cc, N, H, W, ptr(daligned), daligned.shape[-1], ptr(dlogits),
-                                  dlogits.shape[-1], is_bf16(aligned), stream()), "nvq_tsum_backward")
+                                  dlogits.shape[-1], is_bf16(aligned), is_bf16(daligned), stream()), "nvq_tsum_backward")
 
 
 def cbam_channel(gap_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca):
@@ -666,7 +667,7 @@ def axpy_slice(dst: Sl, src: Sl, alpha: float = 1.0, accumulate: bool = True, ma
     assert dst.c == src.c
     check(lib().nvq_axpy_slice(ptr(dst.t), dst.ld, dst.coff, ptr(src.t), src.ld, src.coff,
                                ptr(mask.t) if mask else None, mask.ld if mask else 0, mask.coff if mask else 0,
-                               dst.c, npix, alpha, int(accumulate), stream()), "nvq_axpy_slice")
+                               dst.c, npix, alpha, int(accumulate), src.bf16, stream()), "nvq_axpy_slice")
 
 
 def colsum(x: Sl, out: torch.Tensor, ws, alpha=1.0, accumulate=False):

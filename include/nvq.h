@@ -258,11 +258,12 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
  * per pixel of scratch, 16-byte aligned): gather form - a per-source pass writes the flow gradient and a {corner offset,
  * 4 weights} record, a per-destination pass collects the contributions from the 9x9 window around each pixel; no atomics
  * and a fixed summation order for every source whose flow is shorter than 4 pixels (longer ones are still scattered).
- * feat_bf16: `feat` (read for the flow gradient) is stored as bf16 - gather form only; dout, dfeat, dflow are fp32. */
+ * feat_bf16 / dout_bf16: `feat` (read for the flow gradient) / `dout` are stored as bf16 - gather form only; dfeat and
+ * dflow are fp32. */
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat,
                       int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
                       float* dfeat, int dfeat_ld, float* dflow, int dflow_ld,
-                      float* records, size_t records_bytes, int feat_bf16, void* stream);
+                      float* records, size_t records_bytes, int feat_bf16, int dout_bf16, void* stream);
 
 /* ------------------------------------------------------------------ temporal aggregation
  * TemporalAggregator.forward softmax + weighted sum, super_resolution.py:174,203-204:
@@ -279,7 +280,7 @@ int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, 
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix,
                       const float* aligned, int aligned_ld, const float* attn, int attn_ld,
                       int T, int C, int N, int H, int W, float* daligned, int daligned_ld,
-                      float* dlogits, int dlogits_ld, int aligned_bf16, void* stream);
+                      float* dlogits, int dlogits_ld, int aligned_bf16, int daligned_bf16, void* stream);
 
 /* CBAM, efficient_layers.py:154-228.
  * cbam_channel: gap = mean(weighted); hid = relu(W1 gap); ca = sigmoid(W2 hid).
@@ -334,10 +335,11 @@ int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, in
                                int W, int s, float* du, int du_ld, void* stream);
 
 /* ------------------------------------------------------------------ small helpers */
-/* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C */
+/* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C; src may be stored as
+ * bf16 (src_bf16), dst and mask are fp32 */
 int nvq_axpy_slice(float* dst, int dst_ld, int dst_coff, const float* src, int src_ld,
                    int src_coff, const float* mask, int mask_ld, int mask_coff, int C,
-                   long npix, float alpha, int accumulate, void* stream);
+                   long npix, float alpha, int accumulate, int src_bf16, void* stream);
 /* out[c] (+)= alpha * sum_pixels x[p, coff + c] */
 int nvq_colsum(const float* x, int x_ld, int x_coff, int C, long npix, float alpha,
                float* out, float* workspace, size_t workspace_bytes, int accumulate,

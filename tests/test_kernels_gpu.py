@@ -728,19 +728,27 @@ def test_bf16_stored_feature_tensors(K, C, B, H, W):
     # warp forward (fp32 and bf16 output) and backward
     flow = to_nhwc(rnd(B, 2, H, W, seed=7) * 1.7, 4)
     outs = []
+    dal32 = to_nhwc(bf(rnd(B, T * C, H, W, seed=9)))         # gradient w.r.t. aligned, bf16-representable
     for fb, odt in ((f32, torch.float32), (f16, torch.float32), (f16, torch.bfloat16)):
         wo = torch.zeros(B, H, W, T * C, device="cuda", dtype=odt)
         K.warp_forward(K.Sl(fb).images(0, B), flow, K.Sl(wo, C, 2 * C))
         dfeat, dflow = torch.zeros(B, H, W, C, device="cuda"), torch.empty(B, H, W, 4, device="cuda")
-        K.warp_backward(K.Sl(to_nhwc(rnd(B, T * C, H, W, seed=9)), C, 2 * C), K.Sl(fb).images(0, B), flow, K.Sl(dfeat), dflow)
+        K.warp_backward(K.Sl(dal32.to(odt), C, 2 * C), K.Sl(fb).images(0, B), flow, K.Sl(dfeat), dflow)
         outs.append((wo, dfeat, dflow))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[0][0].bfloat16())
     for k in (1, 2):
         assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
     assert outs[0][0][..., :2 * C].abs().max().item() == 0
-    with pytest.raises(RuntimeError, match="gather form"):
-        K.warp_backward(K.Sl(to_nhwc(rnd(B, T * C, H, W, seed=9)), C, 2 * C), K.Sl(f16).images(0, B), flow,
-                        K.Sl(torch.zeros(B, H, W, C, device="cuda")), torch.empty(B, H, W, 4, device="cuda"), gather=False)
+    for fb, db in ((f16, dal32), (f32, dal32.bfloat16())):
+        with pytest.raises(RuntimeError, match="gather form"):
+            K.warp_backward(K.Sl(db, C, 2 * C), K.Sl(fb).images(0, B), flow, K.Sl(torch.zeros(B, H, W, C, device="cuda")),
+                            torch.empty(B, H, W, 4, device="cuda"), gather=False)
+    # slice axpy with a bf16-stored source
+    d0 = to_nhwc(rnd(B, C, H, W, seed=11))
+    da, db = d0.clone(), d0.clone()
+    K.axpy_slice(K.Sl(da), K.Sl(dal32, C, C), alpha=0.5)
+    K.axpy_slice(K.Sl(db), K.Sl(dal32.bfloat16(), C, C), alpha=0.5)
+    assert torch.equal(da, db) and not torch.equal(da, d0)
     # softmax-weighted sum forward / backward
     lg = to_nhwc(rnd(B, T, H, W, seed=3) * 3, 4)
     outs = []
@@ -753,6 +761,9 @@ def test_bf16_stored_feature_tensors(K, C, B, H, W):
         outs.append((attn, wt, gp, dal, dlg))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    dal16, dlg16 = torch.empty(B, H, W, T * C, device="cuda", dtype=torch.bfloat16), torch.empty(B, H, W, 4, device="cuda")
+    K.tsum_backward(to_nhwc(rnd(B, C, H, W, seed=6)), (rnd(B, C, seed=8) * 0.1).cuda(), a16, outs[1][0], T, C, dal16, dlg16)
+    assert torch.equal(dal16, outs[1][3].bfloat16()) and torch.equal(dlg16, outs[1][4])     # bf16-stored gradient output
     # exact-fp32 correlation refuses bf16-stored inputs
     with pytest.raises(RuntimeError, match="NVQ_MATH_BF16"):
         K.correlation_forward(K.Sl(f16), K.Sl(a16, C, C), torch.empty(N, H, W, 96, device="cuda"), math=K.MATH_F32)
