@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- head conv on the matrix cores (NVQ_MATH_BF16, 3 channels)
-// The 27-term contraction of the 3 -> F head conv as v_mfma_f32_16x16x32_bf16: K index k = dy*12 + dx*4 + ci over a halo
+// The 27-term contraction of the 3 -> F head conv as v_mfma_f32_16x16x32_bf16 (weights rounded to bf16, the frame taken as a
+// hi + lo pair of bf16 values): K index k = dy*12 + dx*4 + ci over a halo
 // tile staged in LDS as bf16 [18][66][4] (3 channels + a zero: 8 B per pixel), so that a lane's 8 consecutive k are two
 // 8-byte pieces = two pixels of the tile; k = 32..35 (the last pixel of the window) takes a second MFMA whose other
 // operands are zero.  Output rows are PERMUTED: row i of block cb is channel (i/4)*(F/4) + 4*cb + i%4, so lane (pixel c,
@@ -118,7 +119,10 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, float* __restrict__ out, int out_ld,
                                                         int out_bf16, __bf16* __restrict__ img8, int tilesX, int tilesY) {
     constexpr int F = 16 * NB, FQ = F / 4;
+    // the frame as hi + lo bf16 pairs (x = hi + lo to ~16 bits): the image is the one operand of the network that is not
+    // already a rounded quantity, and the second pair of MFMAs costs nothing next to the stores
     __shared__ __attribute__((aligned(16))) bf16x4 xs[HM_HH * HM_HW + 4];
+    __shared__ __attribute__((aligned(16))) bf16x4 xl[HM_HH * HM_HW + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     int bt = blockIdx.x;
@@ -152,7 +156,10 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const float* __restrict_
         const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = ok ? (size_t)gy * W + gx : 0;
         const float v0 = img[o], v1 = img[(size_t)H * W + o], v2 = img[(size_t)2 * H * W + o];
-        xs[item] = ok ? (bf16x4){(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)0.f}
+        const bf16x4 hi = ok ? (bf16x4){(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)0.f}
+                             : (bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        xs[item] = hi;
+        xl[item] = ok ? (bf16x4){(__bf16)(v0 - (float)hi[0]), (__bf16)(v1 - (float)hi[1]), (__bf16)(v2 - (float)hi[2]), (__bf16)0.f}
                       : (bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     }
     __syncthreads();
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const float* __restrict_
         const bf16x4 p2 = g == 0 ? xs[base + 2 * HM_HW + 2] : z4;
         const bf16x8 b0 = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
         const bf16x8 b1 = {p2[0], p2[1], p2[2], p2[3], z4[0], z4[1], z4[2], z4[3]};
+        const bf16x4 q0 = xl[base + o0], q1 = xl[base + o1];
+        const bf16x4 q2 = g == 0 ? xl[base + 2 * HM_HW + 2] : z4;
+        const bf16x8 c0 = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        const bf16x8 c1 = {q2[0], q2[1], q2[2], q2[3], z4[0], z4[1], z4[2], z4[3]};
         const int gy = ty * HM_TH + ry, gx = tx * HM_TW + xb + c;
         const bool ok = gy < H && gx < W;
         const size_t pix = (size_t)(n * H + gy) * W + gx;
@@ -176,6 +187,8 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             acc[cb] = (f32x4){bv[cb].x, bv[cb].y, bv[cb].z, bv[cb].w};
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[cb], c0, acc[cb], 0, 0, 0);   // small terms first
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[cb], c1, acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[cb], b0, acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[cb], b1, acc[cb], 0, 0, 0);
 #pragma unroll

@@ -154,8 +154,9 @@ int nvq_head_forward(const float* frames, int B, int T, int Cin, int H, int W,
                      float* out, int out_ld, int out_bf16, float* img8, int math, void* stream);
 /* img8 (optional, bf16 [nslots*B][H][W][8]): the frames themselves in slot order, channels 0..Cin-1 (rest zero) - the
  * x operand with which nvq_conv_wgrad computes the head's weight gradient on the matrix cores in bf16 mode.
- * math: NVQ_MATH_F32 = exact fp32 FMAs; NVQ_MATH_BF16 = frames and weights rounded to bf16, fp32 accumulation on the
- * matrix cores (Cin = 3, F in {16, 32, 64}; other shapes use the fp32 kernel in either mode). */
+ * math: NVQ_MATH_F32 = exact fp32 FMAs; NVQ_MATH_BF16 = weights rounded to bf16, the frame taken as a hi + lo pair of bf16
+ * values (~16 bits), fp32 accumulation on the matrix cores (Cin = 3, F in {16, 32, 64}; other shapes use the fp32 kernel
+ * in either mode). */
 /* dweight[F][Cin][3][3], dbias[F] (+= if accumulate) from (dout + dout2) masked by (act > 0); dout2 may be NULL
  * (it is the skip path of `features = body(h) + h`, summed here instead of in a separate pass). */
 int nvq_head_wgrad(const float* frames, int B, int T, int Cin, int H, int W,

@@ -174,14 +174,14 @@ def test_conv_weight_gradient_slices_and_accumulate(K):
 @pytest.mark.parametrize("Fc,B,T,H,W,out16", [(64, 2, 3, 37, 70, True), (32, 1, 3, 16, 64, True), (16, 2, 1, 5, 9, False),
                                               (64, 1, 3, 40, 130, False)])
 def test_head_forward_matrix_core_mode(K, Fc, B, T, H, W, out16):
-    """NVQ_MATH_BF16 head: frames and weights rounded to bf16, fp32 accumulation (head_mfma_kernel, permuted output rows,
-    second K step for the window's last pixel): equal to the fp32 conv of the rounded operands; border, ragged and multi-tile
-    shapes; fp32 and bf16 outputs; the bf16 NHWC-8 copy of the frames."""
+    """NVQ_MATH_BF16 head: weights rounded to bf16, the frame as a hi + lo pair of bf16 values (~16 bits), fp32 accumulation
+    (head_mfma_kernel, permuted output rows, second K step for the window's last pixel): equal to the fp32 conv of the frame
+    with the rounded weights; border, ragged and multi-tile shapes; fp32 and bf16 outputs; the bf16 NHWC-8 copy of the frames."""
     frames = rnd(B, T, 3, H, W).abs()
     w, b = rnd(Fc, 3, 3, 3, scale=0.4), rnd(Fc, scale=0.1)
     c = T // 2
     slots = [c] + [t for t in range(T) if t != c]
-    ref = torch.stack([F.relu(F.conv2d(bf(frames[:, t]), bf(w), b, padding=1)) for t in slots], 0).reshape(T * B, Fc, H, W)
+    ref = torch.stack([F.relu(F.conv2d(frames[:, t], bf(w), b, padding=1)) for t in slots], 0).reshape(T * B, Fc, H, W)
     out = torch.full((T * B, H, W, Fc), 3.0, device="cuda", dtype=torch.bfloat16 if out16 else torch.float32)
     img8 = torch.full((T * B, H, W, 8), 3.0, device="cuda", dtype=torch.bfloat16)
     K.head_forward(frames.cuda(), slots, w.cuda(), b.cuda(), out, img8=img8, math=K.MATH_BF16)

@@ -286,6 +286,27 @@ def test_bf16_activation_storage_quality(SR):
     assert np.allclose(l1, l2, rtol=1e-2)
 
 
+def test_bf16_feature_storage_switch(SR, monkeypatch):
+    """NVQ_BF16_FEATURES=0 keeps the frames' feature tensors (and the gradient w.r.t. them) in fp32 inside the bf16 mode:
+    both settings run, and differ only by the bf16 rounding of those tensors."""
+    from nerve_cl import _nvq
+    x = synth.formula_clip(2, 3, 32, 40, seed=3).cuda()
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("NVQ_BF16_FEATURES", flag)
+        net, _ = build_pair(SR, 32, 2, 1, 2, True)
+        net.math_mode, net.bf16_activations = _nvq.MATH_BF16, True
+        out, inter = net(x, return_intermediate=True)
+        out.square().mean().backward()
+        res.append((out.detach(), torch.cat([p.grad.flatten() for p in net.parameters()]), inter))
+    assert not torch.equal(res[0][0], res[1][0])
+    mse = (res[0][0] - res[1][0]).pow(2).mean().item()
+    assert 10 * np.log10(1.0 / max(mse, 1e-12)) > 50.0
+    assert F.cosine_similarity(res[0][1], res[1][1], dim=0).item() > 0.999
+    a0, a1 = res[0][2]["aligned"][1], res[1][2]["aligned"][1]          # centre frame: the same values, rounded once to bf16 in run 0
+    assert a0.dtype == a1.dtype == torch.float32 and torch.equal(a0, a1.bfloat16().float())
+
+
 LIGHT = sorted(glob.glob(os.path.join(GOLD, "light_*.npz")))
 
 
