@@ -259,6 +259,7 @@ def main():
                                f"{cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss,
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                    "conv_internal_storage": "bf16" if net.bf16_activations else "f32"},
         "roofline": roofline,
         "residual_stack": residual_stack,
