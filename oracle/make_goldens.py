@@ -271,11 +271,63 @@ def run_light(name, cfg):
     print(f"{name}: loss {loss.item():.6f} clamped {blob['clamped_frac']:.3f} oracle-vs-ref out err {err:.2e}")
 
 
+def run_fr(name, cfg):
+    """FrameRecoveryNet (reference frame_recovery.py:335-446): output, loss, gradients, BatchNorm buffers - the pin of
+    oracle/fr_oracle.py, groundwork for the HIP build of that network."""
+    from nerve_cl.models.frame_recovery import FrameRecoveryNet as RefFR
+    from oracle import fr_oracle
+    base, B, T, H, W, train = cfg
+    sd = synth.formula_state_fr(3, base, gain=GAIN)
+    clip = synth.formula_clip(B, T + 1, H, W)
+    corrupted, refs = clip[:, 0].contiguous(), clip[:, 1:].contiguous()
+    mask = torch.zeros(B, 1, H, W)
+    mask[:, :, H // 4:H // 4 + H // 2, W // 3:W // 3 + W // 2] = 1.0
+    corrupted = corrupted * (1 - mask)                      # the corrupted region carries no signal
+    tgt = synth.formula_target(B, H, W)
+    ref = RefFR(3, base, T)
+    ref.load_state_dict(sd, strict=True)
+    ref.train(train)
+    out = ref(corrupted, refs, mask)
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    o_out = fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, train)
+    F.mse_loss(o_out, tgt).backward()
+    err = (o_out - out).abs().max().item()
+    assert err < 2e-5, f"{name}: oracle != reference output {err:.3e}"
+    ref_sd = ref.state_dict()
+    worst = 0.0
+    for n, p in ref.named_parameters():
+        e = (P[n].grad - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        worst = max(worst, e)
+        assert e < 2e-4, f"{name}: oracle != reference grad {n} {e:.3e}"
+    _, bufs = fr_oracle.shapes(3, base)
+    for n in bufs:
+        assert (P[n].double() - ref_sd[n].double()).abs().max().item() < 1e-5, n
+    blob = {"cfg": np.array([base, B, T, H, W, int(train)], dtype=np.int64), "output": out.detach().numpy(),
+            "loss": np.array(loss.item(), dtype=np.float64)}
+    for n, p in ref.named_parameters():
+        blob["gsum/" + n] = grad_summary(p.grad)
+    for n in bufs:
+        if "num_batches" not in n and ref_sd[n].numel() <= 64:
+            blob["buf/" + n] = ref_sd[n].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
+    print(f"{name}: loss {loss.item():.6f} oracle-vs-ref out err {err:.2e}, worst grad err {worst:.2e}, "
+          f"{sum(p.numel() for p in ref.parameters())} parameters")
+
+
+FR_CASES = {"fr_b16_train": (16, 2, 2, 32, 48, True), "fr_b16_eval": (16, 1, 2, 40, 40, False)}
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     RefSR, RefEWC = import_reference()
+    if "--only-fr" in sys.argv:
+        for name, cfg in FR_CASES.items():
+            run_fr(name, cfg)
+        return
     for name, cfg in LIGHT_CASES.items():
         run_light(name, cfg)
     if "--only-light" in sys.argv:
@@ -285,6 +337,8 @@ def main():
     run_trajectory(RefSR)
     run_ewc(RefSR, RefEWC)
     run_default_init(RefSR)
+    for name, cfg in FR_CASES.items():
+        run_fr(name, cfg)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {OUT}: {total/1024:.0f} KiB")
 

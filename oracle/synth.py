@@ -70,6 +70,19 @@ def _fill(shapes, buffers, gain) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def formula_state_fr(in_channels: int = 3, base: int = 16, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """The same recipe for FrameRecoveryNet's state_dict (oracle/fr_oracle.py).  Its BatchNorm layers are Sequential
+    members ("stem.1.weight"), so a BatchNorm weight is recognised by its shape: 1-D, not a bias."""
+    from . import fr_oracle
+    shapes, buffers = fr_oracle.shapes(in_channels, base)
+    renamed = {(n[:-6] + "bn.weight" if (len(s) == 1 and n.endswith("weight") and not n.endswith("bn.weight")) else n): (n, s)
+               for n, s in shapes.items()}
+    filled = _fill({k: s for k, (_, s) in renamed.items()}, buffers, gain)
+    out = {orig: filled[k] for k, (orig, _) in renamed.items()}
+    out.update({n: filled[n] for n in buffers})
+    return out
+
+
 def formula_clip(B: int, T: int, H: int, W: int, C: int = 3, seed: int = 11) -> torch.Tensor:
     """(B,T,C,H,W) frames in [0,1): a smooth moving pattern plus hash noise, so
     that correlation/flow see real inter-frame structure."""

@@ -137,3 +137,41 @@ def test_light_matches_reference_fixture(path):
             assert _rel(P[key[6:]].grad.numpy(), g[key]) < 1e-4, key
         elif key.startswith("buf/"):
             assert _rel(P[key[4:]].double().numpy(), g[key]) < 1e-5, key
+
+
+FR = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fr_*.npz")))
+
+
+@pytest.mark.parametrize("path", FR, ids=[os.path.basename(p)[:-4] for p in FR])
+def test_frame_recovery_oracle_matches_reference_fixture(path):
+    """oracle/fr_oracle.py (FrameRecoveryNet restatement, groundwork for SURVEY 8f row 1) against the reference's numbers:
+    output, loss, every parameter's gradient summary and the small BatchNorm buffers after one training-mode call."""
+    from oracle import fr_oracle
+    g = np.load(path)
+    base, B, T, H, W, train = [int(v) for v in g["cfg"]]
+    sd = synth.formula_state_fr(3, base, gain=synth.GOLDEN_GAIN)
+    shapes, buffers = fr_oracle.shapes(3, base)
+    assert set(sd) == set(shapes) | set(buffers) and all(tuple(sd[n].shape) == tuple(s) for n, s in shapes.items())
+    clip = synth.formula_clip(B, T + 1, H, W)
+    corrupted, refs = clip[:, 0].contiguous(), clip[:, 1:].contiguous()
+    mask = torch.zeros(B, 1, H, W)
+    mask[:, :, H // 4:H // 4 + H // 2, W // 3:W // 3 + W // 2] = 1.0
+    corrupted = corrupted * (1 - mask)
+    tgt = synth.formula_target(B, H, W)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, bool(train))
+    loss = F.mse_loss(out, tgt)
+    loss.backward()
+    assert _rel(out.detach().numpy(), g["output"]) < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert torch.equal(out * (1 - mask), corrupted * (1 - mask))          # uncorrupted pixels pass through (:439)
+    seen = 0
+    for key in g.files:
+        if key.startswith("gsum/"):
+            ref, got = g[key], grad_summary(P[key[5:]].grad)
+            assert abs(got[1] - ref[1]) <= 2e-4 * max(ref[1], 1e-12), key
+            assert np.abs(got[2:] - ref[2:]).max() <= 2e-4 * max(np.abs(ref[2:]).max(), ref[1] * 1e-2), key
+            seen += 1
+        elif key.startswith("buf/"):
+            assert _rel(P[key[4:]].double().numpy(), g[key]) < 1e-5, key
+    assert seen == len(shapes)
