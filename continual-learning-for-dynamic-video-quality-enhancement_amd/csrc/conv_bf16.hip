@@ -146,9 +146,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int gy = ty * TH_ + hy - HALO, gx = tx * TW + hx - HALO;
         xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        // out-of-image pieces point at their own channel group of pixel 0 (any readable address; masked at commit)
-        xoff[k] = (xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld) : 0u) + 8 * (item & 3);
+        // pixel offset without the channel group (added per chunk); out-of-image pieces use pixel 0 and are masked at commit.
+        // Slice-planar input: the offset inside a 32-channel plane; chunks of the leading in_ld-channel tensor shift it.
+        xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * (d.in_plane ? 32 : d.in_ld)) : 0u;
     }
+    const int nk0 = d.in_plane ? d.in_ld >> 5 : 0x7fffffff;   // chunks that live in the leading tensor (all, if interleaved)
+    const int sh0 = d.in_plane ? __ffs(d.in_ld >> 5) - 1 : 0; // log2(in_ld / 32)
     // Whole halo inside the image and a whole number of chunks: no piece of this tile is ever masked, and the commit can
     // store the registers as they are (with two waves per SIMD every VALU instruction of the staging code competes with
     // the other wave's MFMA issue, so the selects are kept out of the common case).
@@ -163,15 +166,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         const int ch = kc * KCB + chg;
         cv0 = ch < d.cin;
         cv1 = ch + 4 < d.cin;
-        // a channel group past the slice reads the pixel's group 0 instead (xoff includes + chg, so - chg is in range)
-        const int o0 = cv0 ? kc * KCB : -chg, o1 = cv1 ? kc * KCB + 4 : -chg;
+        // a channel group past the slice reads the pixel's group 0 instead (masked at commit)
+        const bool lead = kc < nk0;                           // uniform
+        const int sh = lead ? sh0 : 0;
+        const unsigned cbase = lead ? (unsigned)kc * KCB : (unsigned)kc * d.in_plane;
+        const unsigned o0 = cv0 ? cbase + chg : 0u, o1 = cv1 ? cbase + chg + 4 : 0u;
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             if constexpr (INB) {
-                xr[k][0] = *reinterpret_cast<const u32x4*>(in16 + (xoff[k] + o0));
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
             } else {
-                xr[k][0] = *reinterpret_cast<const u32x4*>(in32 + (xoff[k] + o0));
-                xr[k][XREGS - 1] = *reinterpret_cast<const u32x4*>(in32 + (xoff[k] + o1));
+                xr[k][0] = *reinterpret_cast<const u32x4*>(in32 + ((xoff[k] << sh) + o0));
+                xr[k][XREGS - 1] = *reinterpret_cast<const u32x4*>(in32 + ((xoff[k] << sh) + o1));
             }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
@@ -382,12 +388,18 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
         xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xoff[k] = (xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d3.in_ld) : 0u) + 8 * (item & 3);
+        xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * (d3.in_plane ? 32 : d3.in_ld)) : 0u;
     }
+    const int nk0 = d3.in_plane ? d3.in_ld >> 5 : 0x7fffffff;  // slice-planar input: see conv_bf16_kernel
+    const int sh0 = d3.in_plane ? __ffs(d3.in_ld >> 5) - 1 : 0;
+    const unsigned chg = 8 * (tid & 3);
     u32x4 xr[XPER], wr[WPER], lr;
     auto fetch = [&](int kc) {                                // raw loads only (d3.cin % 32 == 0: no channel masks)
+        const bool lead = kc < nk0;
+        const int sh = lead ? sh0 : 0;
+        const unsigned o0 = (lead ? (unsigned)kc * KCB : (unsigned)kc * d3.in_plane) + chg;
 #pragma unroll
-        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + (xoff[k] + kc * KCB));
+        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
 #pragma unroll
         for (int k = 0; k < WPER; ++k) wr[k] = w3p[(size_t)kc * (WS3 / 8) + tid + k * 256];
         lr = wlp[(size_t)kc * (WSL / 8) + tid];
@@ -588,6 +600,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
     const int xq = XCH * (tid & (XPP - 1));          // channel offset of this thread's X pieces inside the chunk
     const int yq = YCH * (tid & (YPP - 1));
     const bool xch_ok = cic * CIC + xq < d.cin;
+    // slice-planar x (nvq_wgrad_desc::x_plane): this thread's channels lie in the leading x_ld-channel tensor or in one
+    // compact 32-channel plane; either way its pieces are  x + pixel * xmul + xbase
+    const int xch = cic * CIC + xq;
+    const bool xlead = !d.x_plane || xch < d.x_ld;
+    const unsigned xmul = xlead ? d.x_ld : 32;
+    const size_t xbase = xlead ? (size_t)xch : (size_t)(xch >> 5) * d.x_plane + (xch & 31);
     const int ych = coc * COC + yq;
     const bool ych_ok = ych < d.cout;
     // all loads unconditional (invalid pieces read element 0 of the slice); the validity masks are applied in
@@ -607,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
             const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch_ok;
             xmask |= (ok ? 1u : 0u) << k;
-            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + cic * CIC + xq : 0;
+            const size_t off = ok ? ((size_t)(n * H + gy) * W + gx) * xmul + xbase : 0;
             if constexpr (XB) xr[k] = *reinterpret_cast<const u32x4*>(x16 + off);
             else xr[k] = *reinterpret_cast<const u32x4*>(x32 + off);
         }

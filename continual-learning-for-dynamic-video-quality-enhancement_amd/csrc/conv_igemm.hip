@@ -482,6 +482,13 @@ static int epilogue_vec_ok(const nvq_conv_desc& d) {
     return v;
 }
 
+// nvq_conv_desc::in_plane: bf16 input, whole 32-channel chunks, one plane = n*h*w*32 elements, 32-bit element offsets
+static bool planar_input_ok(const nvq_conv_desc& d) {
+    return d.math == NVQ_MATH_BF16 && d.in_bf16 && d.cin % 32 == 0 && d.in_coff == 0 &&
+           (d.in_ld == 32 || d.in_ld == 64 || d.in_ld == 128) && d.in_ld <= d.cin &&
+           (size_t)d.in_plane == (size_t)d.n * d.h * d.w * 32 && (size_t)(d.cin / 32) * d.in_plane < ((size_t)1 << 32);
+}
+
 int nvq_rdb_tail_forward(const nvq_conv_desc* d3p, const nvq_conv_desc* dlp, void* stream) {
     const nvq_conv_desc d3 = *d3p, dl = *dlp;
     NVQ_REQUIRE(d3.math == NVQ_MATH_BF16 && dl.math == NVQ_MATH_BF16 && d3.in_bf16 && dl.in_bf16,
@@ -489,8 +496,16 @@ int nvq_rdb_tail_forward(const nvq_conv_desc* d3p, const nvq_conv_desc* dlp, voi
     NVQ_REQUIRE(d3.ksize == 3 && dl.ksize == 1 && d3.cout == 32 && d3.cout_store == 32 && dl.cout == 64 && dl.cout_store == 64,
                 "rdb_tail_forward: 3x3 -> 32 channels followed by 1x1 -> 64 channels");
     NVQ_REQUIRE(d3.cin % 32 == 0 && dl.cin == d3.cin + 32 && dl.in == d3.in && dl.in_ld == d3.in_ld && dl.in_coff == d3.in_coff &&
-                    d3.out == (float*)d3.in && d3.out_ld == d3.in_ld && d3.out_coff == d3.in_coff + d3.cin && d3.out_bf16,
-                "rdb_tail_forward: the 3x3 layer must write channels [cin, cin+32) of the buffer both convs read");
+                    dl.in_plane == d3.in_plane && d3.out_bf16,
+                "rdb_tail_forward: both convs must read the same buffer");
+    if (d3.in_plane) {       // slice-planar buffer: y4 is the compact plane number cin / 32
+        NVQ_REQUIRE(planar_input_ok(d3) && d3.out_ld == 32 && d3.out_coff == 0 &&
+                        (const char*)d3.out == (const char*)d3.in + (size_t)(d3.cin / 32) * d3.in_plane * 2,
+                    "rdb_tail_forward: the 3x3 layer must write plane cin/32 of the slice-planar buffer both convs read");
+    } else {
+        NVQ_REQUIRE(d3.out == (float*)d3.in && d3.out_ld == d3.in_ld && d3.out_coff == d3.in_coff + d3.cin,
+                    "rdb_tail_forward: the 3x3 layer must write channels [cin, cin+32) of the buffer both convs read");
+    }
     NVQ_REQUIRE(d3.n == dl.n && d3.h == dl.h && d3.w == dl.w && d3.n > 0 && d3.h > 0 && d3.w > 0, "rdb_tail_forward: shapes");
     NVQ_REQUIRE(d3.in_ld % 8 == 0 && d3.in_coff % 8 == 0 && aligned16(d3.in) && aligned16(d3.wpack) && aligned16(dl.wpack),
                 "rdb_tail_forward: alignment");
@@ -516,6 +531,9 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     NVQ_REQUIRE(d.out_coff + d.cout_store <= d.out_ld, "conv_forward: output slice exceeds ld");
     NVQ_REQUIRE(aligned16(d.wpack), "conv_forward: wpack alignment");
     NVQ_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0, "conv_forward: empty shape");
+    NVQ_REQUIRE(!d.in_plane || planar_input_ok(d),
+                "conv_forward: a slice-planar input needs NVQ_MATH_BF16, bf16 storage, cin %% 32 == 0, in_coff 0, in_ld in "
+                "{32, 64, 128} and in_plane = n*h*w*32 (cin %d ld %d plane %u)", d.cin, d.in_ld, d.in_plane);
     NVQ_REQUIRE(d.center_cin >= 0 && d.center_cin % 32 == 0 && d.center_cin <= d.cin && (d.center_cin == 0 || d.ksize == 3),
                 "conv_forward: center_cin %d (3x3 only, multiple of 32, <= cin %d)", d.center_cin, d.cin);
     const int NT = choose_nt(d.cout);
@@ -577,6 +595,11 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     NVQ_REQUIRE(d.math != NVQ_MATH_BF16 || d.dy_coff + ((d.cout + 3) & ~3) <= d.dy_ld,
                 "conv_wgrad(bf16): the dy slice must be readable up to a multiple of 4 channels");
     NVQ_REQUIRE(d.workspace_bytes >= nvq_wgrad_workspace_bytes(), "conv_wgrad: workspace too small");
+    NVQ_REQUIRE(!d.x_plane || (d.math == NVQ_MATH_BF16 && d.x_bf16 && d.x_coff == 0 && d.cin % 32 == 0 &&
+                               (d.x_ld == 32 || d.x_ld == 64 || d.x_ld == 128) && d.x_ld <= d.cin &&
+                               (size_t)d.x_plane == (size_t)d.n * d.h * d.w * 32),
+                "conv_wgrad: a slice-planar x needs NVQ_MATH_BF16, bf16 storage, cin %% 32 == 0, x_coff 0, x_ld in {32, 64, 128} "
+                "and x_plane = n*h*w*32");
     const int taps = d.ksize * d.ksize;
     const int nci = (d.cin_w + WG_C - 1) / WG_C, nco = (d.cout + WG_C - 1) / WG_C;
     const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;

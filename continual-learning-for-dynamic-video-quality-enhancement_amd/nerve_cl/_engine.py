@@ -199,12 +199,17 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     K.cbam_channel(gap_partial, nblk, F, g.R, B, H * W, w1, w2, gap, hid, ca)
     sm, amax, sa = _new(dev, B, H, W, 2), _new(dev, B, H, W, dtype=torch.int32), _new(dev, B, H, W)
     K.cbam_pool(weighted, ca, sm, amax)
-    cats = [_new(dev, B, H, W, g.CATLD, dtype=act_dtype) for _ in range(nblocks)]
+    # bf16 mode: slice-planar dense-block buffers (K.CatBuf: x and every growth slice compact tensors of their own, whole
+    # 128-B lines written by every layer); NVQ_PLANAR=0 or fp32 storage: one interleaved [B,H,W,CATLD] tensor per block
+    planar = (act_dtype == torch.bfloat16 and math == K.MATH_BF16 and F in (32, 64, 128)
+              and os.environ.get("NVQ_PLANAR", "1") != "0")
+    cats = [K.CatBuf(dev, B, H, W, F, LAYERS, g.CATLD, act_dtype, planar) for _ in range(nblocks)]
+    sv.planar = planar
     # (with no dense blocks the CBAM kernel, an fp32 writer, fills this tensor)
     resout = _new(dev, B, H, W, F, dtype=act_dtype if nblocks else torch.float32)
 
     def xloc(k):  # where the input of block k / the output of block k-1 lives
-        return Sl(cats[k], F, 0) if k < nblocks else Sl(resout)
+        return cats[k].x() if k < nblocks else Sl(resout)
     K.cbam_spatial_apply(weighted, ca, sm, w7, sa, xloc(0))
     sv.a1, sv.a2, sv.attn, sv.weighted = a1, a2, attn, weighted
     sv.gap, sv.hid, sv.ca, sv.sm, sv.amax, sv.sa, sv.nblk = gap, hid, ca, sm, amax, sa, nblk
@@ -221,20 +226,20 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         for i in range(LAYERS - 1 if fuse_tail else LAYERS):
             cin = F + GROWTH * i
             wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
-            K.conv_forward(Sl(cat, cin, 0), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
-                           Sl(cat, GROWTH, cin), 3, relu=True, math=math,
+            K.conv_forward(cat.inp(cin), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
+                           cat.y(i), 3, relu=True, math=math,
                            bits=sv.bits[k][i] if use_bits else None, bits_mode=1 if use_bits else 0)
         wl = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
         if fuse_tail:
             i = LAYERS - 1
             cin = F + GROWTH * i
             w3 = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
-            K.rdb_tail_forward(Sl(cat, cin, 0), w3, P[f"residual_blocks.{k}.layers.{i}.0.bias"], Sl(cat, GROWTH, cin), wl,
-                               P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), alpha=0.2, res=Sl(cat, F, 0),
+            K.rdb_tail_forward(cat.inp(cin), w3, P[f"residual_blocks.{k}.layers.{i}.0.bias"], cat.y(i), wl,
+                               P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), alpha=0.2, res=cat.x(),
                                bits=sv.bits[k][i] if use_bits else None)
         else:
-            K.conv_forward(Sl(cat, g.CAT, 0), wl, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
-                           res=Sl(cat, F, 0), math=math)
+            K.conv_forward(cat.inp(g.CAT), wl, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
+                           res=cat.x(), math=math)
 
     K.TIMER_TAG = ""
     # ---- global fusion + upsampler tail
@@ -296,9 +301,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
     # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
-    dcats = [_new(dev, B, H, W, g.CATLD, dtype=act_dtype), _new(dev, B, H, W, g.CATLD, dtype=act_dtype)] if nb else []
+    dcats = [K.CatBuf(dev, B, H, W, F, LAYERS, g.CATLD, act_dtype, sv.planar) for _ in range(2)] if nb else []
     dagg = _new(dev, B, H, W, F)
-    gout = Sl(dcats[(nb - 1) & 1], F, 0) if nb else Sl(dagg)
+    gout = dcats[(nb - 1) & 1].x() if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
     _capture("dfused", dfeat_c)
     _capture("dres", gout.t[..., :F].float())
@@ -318,23 +323,23 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         cat = sv.cats[k]
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
-        gout = Sl(dcat, F, 0)
-        _wgrad(Sl(cat, g.CAT, 0), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
+        gout = dcat.x()
+        _wgrad(cat.inp(g.CAT), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
         wpb = mirror[k * (LAYERS + 1):(k + 1) * (LAYERS + 1)]     # packs of Wb_4 .. Wb_0, Wb_x
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
-            dy = Sl(dcat, GROWTH, cinb)                      # slot of dy_i
+            dy = dcat.y(LAYERS - 1 - i)                      # slot of dy_i (channels [cinb, cinb + 32) of the buffer)
             if sv.bits is not None:
-                K.conv_forward(Sl(dcat, cinb, 0), wpb[LAYERS - 1 - i], None, dy, 3,
+                K.conv_forward(dcat.inp(cinb), wpb[LAYERS - 1 - i], None, dy, 3,
                                math=math, bits=sv.bits[k][i], bits_mode=2, center_cin=ctr)
             else:
-                K.conv_forward(Sl(dcat, cinb, 0), wpb[LAYERS - 1 - i], None, dy, 3,
-                               mask=Sl(cat, GROWTH, F + GROWTH * i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
+                K.conv_forward(dcat.inp(cinb), wpb[LAYERS - 1 - i], None, dy, 3,
+                               mask=cat.y(i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
             cin = F + GROWTH * i
-            _wgrad(Sl(cat, cin, 0), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
+            _wgrad(cat.inp(cin), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
                    math=math)
-        nxt = Sl(dcats[(k - 1) & 1], F, 0) if k > 0 else Sl(dagg)
-        K.conv_forward(Sl(dcat, g.CAT, 0), wpb[LAYERS], None, nxt, 3, res=gout, math=math, center_cin=ctr)
+        nxt = dcats[(k - 1) & 1].x() if k > 0 else Sl(dagg)
+        K.conv_forward(dcat.inp(g.CAT), wpb[LAYERS], None, nxt, 3, res=gout, math=math, center_cin=ctr)
     K.TIMER_TAG = ""
     dprev = Sl(dagg)
 

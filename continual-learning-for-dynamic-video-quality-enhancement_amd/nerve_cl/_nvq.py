@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
         ("accumulate", ci),
         ("math", ci),
         ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
-        ("bits", vp), ("bits_mode", ci), ("center_cin", ci),
+        ("bits", vp), ("bits_mode", ci), ("center_cin", ci), ("in_plane", C.c_uint),
     ]
 
 
@@ -61,7 +61,7 @@ class WgradDesc(C.Structure):
         ("workspace", vp), ("workspace_bytes", sz),
         ("n", ci), ("h", ci), ("w", ci), ("ksize", ci),
         ("alpha", cf), ("accumulate", ci), ("math", ci),
-        ("x_bf16", ci), ("dy_bf16", ci),
+        ("x_bf16", ci), ("dy_bf16", ci), ("x_plane", C.c_uint),
     ]
 
 
@@ -173,13 +173,15 @@ class Sl:
     """A channel slice of an NHWC activation buffer (fp32, or bf16 for conv-internal tensors):
     tensor [N,H,W,ld], channels [coff, coff+c); ld / coff count elements of the tensor's dtype."""
 
-    __slots__ = ("t", "ld", "coff", "c")
+    __slots__ = ("t", "ld", "coff", "c", "plane")
 
-    def __init__(self, t: torch.Tensor, c: Optional[int] = None, coff: int = 0):
+    def __init__(self, t: torch.Tensor, c: Optional[int] = None, coff: int = 0, plane: int = 0):
+        """plane != 0 (conv / weight-gradient INPUTS only): `t` is the leading tensor of a slice-planar buffer (CatBuf) and
+        the c channels continue in the compact 32-channel planes behind it (nvq_conv_desc::in_plane)."""
         assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.is_contiguous()
-        self.t, self.ld, self.coff = t, t.shape[-1], coff
+        self.t, self.ld, self.coff, self.plane = t, t.shape[-1], coff, plane
         self.c = t.shape[-1] - coff if c is None else c
-        assert self.coff + self.c <= self.ld
+        assert self.coff + self.c <= self.ld or (plane and coff == 0)
 
     @property
     def n(self):
@@ -190,11 +192,41 @@ class Sl:
         return int(self.t.dtype == torch.bfloat16)
 
     def images(self, lo: int, hi: int) -> "Sl":
+        assert not self.plane
         return Sl(self.t[lo:hi], self.c, self.coff)
 
     def base(self) -> int:
         """address of channel `coff` of pixel 0"""
         return ptr(self.t, self.coff)
+
+
+class CatBuf:
+    """The buffer of one residual dense block: [x (F channels) | 32-channel slices ...] (forward: x, y_0 .. y_4; backward:
+    gout, dy_4 .. dy_0).  Interleaved: one [N,H,W,ld] tensor, a slice = a channel range (torch.cat for free).  Slice-planar
+    (planar=True, bf16): x and every slice are compact tensors of their own in one allocation, so a layer's 64-byte pixel
+    rows fill whole 128-byte lines; the convs / weight gradients that read a channel prefix take it through `inp()`."""
+
+    def __init__(self, dev, N: int, H: int, W: int, F: int, nslices: int, ld: int, dtype, planar: bool):
+        self.F, self.planar = F, planar
+        if planar:
+            assert dtype == torch.bfloat16 and F in (32, 64, 128)
+            npx = N * H * W
+            self.plane = npx * 32
+            self.flat = torch.empty((F // 32 + nslices) * self.plane, dtype=dtype, device=dev)
+            self.lead = self.flat[:npx * F].view(N, H, W, F)
+            self.slices = [self.flat[(F // 32 + j) * self.plane:(F // 32 + j + 1) * self.plane].view(N, H, W, 32)
+                           for j in range(nslices)]
+        else:
+            self.t = torch.empty((N, H, W, ld), dtype=dtype, device=dev)
+
+    def x(self) -> Sl:
+        return Sl(self.lead) if self.planar else Sl(self.t, self.F, 0)
+
+    def y(self, j: int) -> Sl:
+        return Sl(self.slices[j]) if self.planar else Sl(self.t, 32, self.F + 32 * j)
+
+    def inp(self, cin: int) -> Sl:
+        return Sl(self.lead, cin, 0, plane=self.plane) if self.planar else Sl(self.t, cin, 0)
 
 
 class KernelTimer:
@@ -367,6 +399,7 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
         assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape) == (n, h, w) and bits.is_contiguous()
         d.bits, d.bits_mode = ptr(bits), bits_mode
     d.center_cin = center_cin
+    d.in_plane = x.plane
     return d
 
 
@@ -403,7 +436,7 @@ def rdb_tail_forward(x: Sl, w3: torch.Tensor, b3, y4: Sl, wl: torch.Tensor, bl, 
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
     d3 = _conv_desc(x, w3, b3, y4, 3, relu=True, math=MATH_BF16, bits=bits, bits_mode=1 if bits is not None else 0)
-    xl = Sl(x.t, x.c + y4.c, x.coff)
+    xl = Sl(x.t, x.c + y4.c, x.coff, plane=x.plane)
     dl = _conv_desc(xl, wl, bl, out, 1, alpha=alpha, res=res, math=MATH_BF16)
     check(lib().nvq_rdb_tail_forward(C.byref(d3), C.byref(dl), stream()), "nvq_rdb_tail_forward")
     if ev0 is not None:
@@ -440,7 +473,7 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.workspace, d.workspace_bytes = ptr(ws), ws.numel() * ws.element_size()
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
-    d.x_bf16, d.dy_bf16 = x.bf16, dy.bf16
+    d.x_bf16, d.dy_bf16, d.x_plane = x.bf16, dy.bf16, x.plane
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
         TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,

@@ -100,6 +100,13 @@ typedef struct nvq_conv_desc {
      * 0.2*lff^T part of the mirror-form dense-block gradient convs, nvq_rdb_backward_weights), so the kernel may skip the
      * other eight taps of those channels.  Multiple of 32, <= cin; 0 = no such channels.  Results do not depend on it. */
     int center_cin;
+    /* Slice-planar input (NVQ_MATH_BF16, bf16 input, cin % 32 == 0, in_coff == 0): in_plane = elements of one 32-channel
+     * plane = n*h*w*32.  The first in_ld channels (in_ld in {32, 64, 128}) are an ordinary [n][h][w][in_ld] tensor at `in`;
+     * every further 32-channel chunk kc (>= in_ld/32) is a compact [n][h][w][32] tensor at in + kc*in_plane - the layout in
+     * which a dense block's buffer is [x | y_0 | y_1 | ...] as separate tensors in one allocation, so that every 64-byte
+     * pixel row a layer writes shares its 128-byte line with the next pixel, not with another layer.  0 = the usual
+     * interleaved buffer.  Outputs, residuals and masks are ordinary (ld, coff) slices of those tensors in either case. */
+    unsigned in_plane;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
@@ -139,6 +146,7 @@ typedef struct nvq_wgrad_desc {
     int n, h, w, ksize;
     float alpha; int accumulate; int math;
     int x_bf16, dy_bf16;                /* storage type of x / dy (see nvq_conv_desc); need NVQ_MATH_BF16 */
+    unsigned x_plane;                   /* slice-planar x (see nvq_conv_desc::in_plane; bf16 x, x_coff == 0); 0 = interleaved */
 } nvq_wgrad_desc;
 size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */
 int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);

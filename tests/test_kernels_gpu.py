@@ -698,6 +698,69 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
     assert rel(from_nhwc(dx2), x2.grad) < TOL
 
 
+@pytest.mark.parametrize("Fc,N,H,W", [(64, 2, 19, 37), (64, 1, 16, 32), (32, 2, 9, 20)])
+def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
+    """nvq_conv_desc::in_plane / nvq_wgrad_desc::x_plane: the dense-block buffer as compact tensors [x | y_0 | ..] in one
+    allocation (K.CatBuf).  Dense layers, the fused tail (F = 64), the mirror-style 1x1 / 3x3 convs over a channel prefix
+    and the weight gradients give bit-identical results to the interleaved buffer."""
+    CAT, ld = Fc + 160, 256
+    full = bf(rnd(N, CAT, H, W))
+    inter = K.CatBuf("cuda", N, H, W, Fc, 5, ld, torch.bfloat16, planar=False)
+    inter.t.zero_()
+    inter.t[..., :CAT] = to_nhwc(full).bfloat16()
+    plan = K.CatBuf("cuda", N, H, W, Fc, 5, ld, torch.bfloat16, planar=True)
+    plan.lead.copy_(inter.t[..., :Fc])
+    for j in range(5):
+        plan.slices[j].copy_(inter.t[..., Fc + 32 * j:Fc + 32 * (j + 1)])
+    ws = ws_tensor(K)
+    for i in (0, 1, 3):                                      # dense layer i: prefix of Fc + 32 i channels -> slice i
+        cin = Fc + 32 * i
+        w3, b3 = rnd(32, cin, 3, 3, scale=0.1, seed=i), rnd(32, seed=20 + i)
+        wp = K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16)
+        bits = [torch.zeros(N, H, W, dtype=torch.int32, device="cuda") for _ in range(2)]
+        for buf, bt in ((inter, bits[0]), (plan, bits[1])):
+            K.conv_forward(buf.inp(cin), wp, b3.cuda(), buf.y(i), 3, relu=True, math=K.MATH_BF16, bits=bt, bits_mode=1)
+        assert torch.equal(inter.t[..., cin:cin + 32], plan.slices[i]) and torch.equal(bits[0], bits[1])
+        dws = []
+        for buf in (inter, plan):                            # weight gradient of the same layer: x = the prefix
+            dw, db = torch.empty(32, cin, 3, 3, device="cuda"), torch.empty(32, device="cuda")
+            K.conv_wgrad(buf.inp(cin), cin, buf.y(4), dw, db, ws, 3, math=K.MATH_BF16)
+            dws.append((dw, db))
+        assert torch.equal(dws[0][0], dws[1][0]) and torch.equal(dws[0][1], dws[1][1])
+    # 1x1 over all channels (lff) with residual x, 64-channel output into the next block's x; its weight gradient
+    wl, bl = rnd(Fc, CAT, 1, 1, scale=0.1, seed=7), rnd(Fc, seed=8)
+    wlp = K.conv_pack(wl.cuda(), False, CAT, math=K.MATH_BF16)
+    nxt = [K.CatBuf("cuda", N, H, W, Fc, 5, ld, torch.bfloat16, planar=pl) for pl in (False, True)]
+    for buf, nb in zip((inter, plan), nxt):
+        K.conv_forward(buf.inp(CAT), wlp, bl.cuda(), nb.x(), 1, alpha=0.2, res=buf.x(), math=K.MATH_BF16)
+    assert torch.equal(nxt[0].t[..., :Fc], nxt[1].lead)
+    dws = []
+    for buf, nb in zip((inter, plan), nxt):
+        dw, db = torch.empty(Fc, CAT, 1, 1, device="cuda"), torch.empty(Fc, device="cuda")
+        K.conv_wgrad(buf.inp(CAT), CAT, nb.x(), dw, db, ws, 1, alpha=0.2, math=K.MATH_BF16)
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1])
+    # 3x3 over all channels -> 64 (the block-input gradient conv) with the centre-tap hint
+    wx = rnd(Fc, CAT, 3, 3, scale=0.1, seed=9)
+    wx[:, :Fc, [0, 0, 0, 1, 1, 2, 2, 2], [0, 1, 2, 0, 2, 0, 1, 2]] = 0
+    wxp = K.conv_pack(wx.cuda(), False, CAT, math=K.MATH_BF16)
+    outs = []
+    for buf in (inter, plan):
+        o = torch.empty(N, H, W, Fc, device="cuda", dtype=torch.bfloat16)
+        K.conv_forward(buf.inp(CAT), wxp, None, K.Sl(o), 3, res=buf.x(), math=K.MATH_BF16, center_cin=Fc if Fc % 32 == 0 else 0)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    if Fc == 64:                                             # fused tail: last dense layer + lff in one launch
+        cin = Fc + 128
+        w3, b3 = rnd(32, cin, 3, 3, scale=0.1, seed=11), rnd(32, seed=12)
+        w3p = K.conv_pack(w3.cuda(), False, cin, math=K.MATH_BF16)
+        for buf, nb in zip((inter, plan), nxt):
+            K.rdb_tail_forward(buf.inp(cin), w3p, b3.cuda(), buf.y(4), wlp, bl.cuda(), nb.x(), alpha=0.2, res=buf.x())
+        assert torch.equal(inter.t[..., cin:cin + 32], plan.slices[4]) and torch.equal(nxt[0].t[..., :Fc], nxt[1].lead)
+    with pytest.raises(RuntimeError, match="slice-planar"):
+        K.conv_forward(K.Sl(plan.lead, Fc + 32, 0, plane=plan.plane + 32), wp, None, plan.y(4), 3, math=K.MATH_BF16)
+
+
 @pytest.mark.parametrize("C,B,H,W", [(64, 2, 19, 37), (32, 1, 9, 20)])
 def test_bf16_stored_feature_tensors(K, C, B, H, W):
     """The storage flags of the non-conv readers of the feature tensors (correlation on the matrix cores, warp, softmax-
