@@ -36,7 +36,7 @@ def pmc_traffic(kernel: str, batch: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE collected
     in two separate passes of this script at the default batch, corrected as MI355X_MICROARCH.md prescribes).
     bench.py cannot collect PMC counters itself; returns None when no matching summary exists."""
-    path = os.path.join(REPO, "profiles", "r01_v4_traffic_pmc.json")
+    path = os.path.join(REPO, "profiles", "r01_v5_traffic_pmc.json")
     if batch != 8 or not os.path.exists(path):
         return None
     try:
@@ -217,7 +217,7 @@ def main():
             gbs = d["bytes"] / (d["ms_total"] * 1e-3) / 1e9
             traffic = pmc_traffic(name, B) if args.math == "bf16" and not args.fp32_acts else None
             common = {"traffic": traffic, "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
-                                                          "profiles/r01_v4_traffic_pmc.json)" if traffic else None,
+                                                          "profiles/r01_v5_traffic_pmc.json)" if traffic else None,
                       "algorithmic_gb_per_launch": d["bytes"] / d["launches"] / 1e9,
                       "kernel": name, "launches": d["launches"],
                       "avg_launch_ms": d["ms_total"] / d["launches"],
