@@ -405,7 +405,10 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
                                mask_c1=chans[li], math=math)
             else:
-                K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, cout_store=K.pad4(chans[li]), math=math)
+                # gradient of the correlation volume: the bf16 volume's 128-channel rows are written whole (zeros behind the
+                # 81 real channels) - a row of 84 channels would leave its second 128-B line half written (a fill read)
+                full = dx_t.shape[-1] if dx_t.dtype == torch.bfloat16 else K.pad4(chans[li])
+                K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, cout_store=full, math=math)
             dy_t, dy_c = dx_t, chans[li]
         dcorr = dy_t
         _capture("f1", acts[1])
