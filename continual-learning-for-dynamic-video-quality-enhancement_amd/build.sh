@@ -6,9 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
+# every object depends on every header (csrc/*.h are shared between translation units: a stale object would link
+# mixed tile / pack layouts without any error)
+newest_header=$(ls -t csrc/*.h ../include/*.h | head -1)
 for f in csrc/*.hip; do
   o=build/$(basename "${f%.hip}").o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/common.h -nt "$o" ] || [ ../include/nvq.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_header" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -152,6 +152,13 @@ def require_device(t: torch.Tensor, what: str = "tensor") -> None:
             "on an AMD GPU (move the model and its inputs to 'cuda'); there is no CPU fallback.")
 
 
+def device_guard(dev: torch.device):
+    """Context that makes `dev` the current HIP device: libnvq launches on the CURRENT device's stream, so a tensor on
+    cuda:1 must not be handed to a launch issued while cuda:0 is current."""
+    import contextlib
+    return torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()
+
+
 def is_bf16(t: Optional[torch.Tensor]) -> int:
     return int(t is not None and t.dtype == torch.bfloat16)
 

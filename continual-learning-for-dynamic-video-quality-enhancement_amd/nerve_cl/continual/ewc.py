@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from nerve_cl import _engine, _nvq, parallel
+from nerve_cl._bucket import BucketedNet
 
 
 def _flat_views(flat: torch.Tensor, named: "List[tuple]") -> Dict[str, torch.Tensor]:
@@ -32,29 +33,115 @@ def _flat_views(flat: torch.Tensor, named: "List[tuple]") -> Dict[str, torch.Ten
     return out
 
 
+class _Segment:
+    """One flat bucket of the penalty: either all parameters of one bucketed network (``net`` set: Fisher / theta* are
+    stored in that network's gradient-bucket layout, so the penalty gradient is ONE accumulate kernel into the bucket) or
+    a plain concatenation of loose parameters (``net`` None: e.g. the engine's ``enhancement_strength``)."""
+
+    def __init__(self, net: Optional[BucketedNet], named: "List[tuple]"):
+        self.net, self.named = net, named          # named: [(full name, parameter)]
+        self.names = [n for n, _ in named]
+
+    def numel(self) -> int:
+        if self.net is not None:
+            return self.net._bucket_layout()[1]
+        return sum(p.numel() for _, p in self.named)
+
+    def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if self.net is None:
+            return _flat_views(flat, self.named)
+        local = self.net._bucket_views(flat)
+        return {full: local[loc] for (full, _), loc in zip(self.named, self.net._param_names)}
+
+    def theta(self) -> torch.Tensor:
+        if self.net is not None:
+            return self.net.flat_theta()           # persistent flat view of the parameters: no per-step cat
+        return torch.cat([p.detach().reshape(-1).float() for _, p in self.named])
+
+    def grads(self) -> Optional[torch.Tensor]:
+        """Flat gradient of the last backward in this segment's layout (None when nothing arrived)."""
+        if self.net is not None:
+            return self.net._last_grad_bucket
+        if all(p.grad is None for _, p in self.named):
+            return None
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1).float()
+                          for _, p in self.named])
+
+
+def segments_of(model: nn.Module) -> "List[_Segment]":
+    """Split model.named_parameters() (requires_grad only, reference ewc.py:67-71) into bucketed networks + loose rest."""
+    owner: Dict[int, "tuple[BucketedNet, str]"] = {}
+    for prefix, m in model.named_modules():
+        if isinstance(m, BucketedNet) and all(p.requires_grad for p in m.parameters()):
+            for p in m.parameters():
+                owner.setdefault(id(p), (m, prefix))
+    segs: "Dict[int, _Segment]" = {}
+    order: "List[_Segment]" = []
+    loose: "List[tuple]" = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        own = owner.get(id(p))
+        if own is None:
+            loose.append((name, p))
+            continue
+        net = own[0]
+        if id(net) not in segs:
+            segs[id(net)] = _Segment(net, [])
+            order.append(segs[id(net)])
+        segs[id(net)].named.append((name, p))
+    for sg in order:
+        sg.names = [n for n, _ in sg.named]
+        assert len(sg.named) == len(sg.net._param_names)
+    if loose:
+        order.append(_Segment(None, loose))
+    return order
+
+
 class _PenaltyFn(torch.autograd.Function):
-    """lambda/2 * sum F (theta - theta*)^2 over a list of parameter tensors."""
+    """lambda/2 * sum F (theta - theta*)^2 over one segment (reference ewc.py:225-232).
+
+    Backward, bucketed network whose own backward is still to come in this pass (the usual ``loss = mse + penalty``
+    order: autograd runs the later-created node first): the term ``go * lambda * F * (theta - theta*)`` is queued on the
+    network and added to its flat gradient bucket by one kernel after the data-parallel all-reduce; no per-tensor
+    gradients are returned, so autograd performs no AccumulateGrad additions for it.  Otherwise (loose parameters, or
+    the network's backward already ran): the gradient is written by the same kernel into a fresh flat tensor and its
+    views are returned."""
 
     @staticmethod
-    def forward(ctx, lam: float, star: torch.Tensor, fisher: torch.Tensor, *params):
-        theta = torch.cat([p.detach().reshape(-1) for p in params])
+    def forward(ctx, seg: _Segment, lam: float, star: torch.Tensor, fisher: torch.Tensor, *params):
+        theta = seg.theta() if seg is not None else torch.cat([p.detach().reshape(-1).float() for p in params])
         out = torch.empty(1, dtype=torch.float32, device=theta.device)
-        _nvq.ewc_penalty(theta, star, fisher, float(lam), out, _engine.workspace(theta.device))
-        ctx.lam, ctx.theta, ctx.star, ctx.fisher = float(lam), theta, star, fisher
+        with _nvq.device_guard(theta.device):
+            _nvq.ewc_penalty(theta, star, fisher, float(lam), out, _engine.workspace(theta.device))
+        ctx.seg, ctx.lam, ctx.star, ctx.fisher = seg, float(lam), star, fisher
+        # a bucketed segment reads theta again at backward time from the persistent flat view (same values)
+        ctx.theta = None if (seg is not None and seg.net is not None) else theta
         ctx.shapes = [p.shape for p in params]
         return out.reshape(())
 
     @staticmethod
     def backward(ctx, go):
-        g = torch.empty_like(ctx.theta)
+        seg = ctx.seg
         scale = go.detach().to(torch.float32).reshape(1).contiguous()
-        _nvq.ewc_penalty_grad(ctx.theta, ctx.star, ctx.fisher, ctx.lam, scale, g, False)
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = int(torch.Size(shp).numel())
-            grads.append(g[off:off + n].view(shp))
-            off += n
-        return (None, None, None) + tuple(grads)
+        net = seg.net if seg is not None else None
+        if net is not None and net._awaiting_backward and getattr(net, "fuse_penalty_gradient", True):
+            net._deferred_adds.append((ctx.lam, ctx.star, ctx.fisher, scale))
+            return (None, None, None, None) + (None,) * len(ctx.shapes)
+        theta = net.flat_theta() if net is not None else ctx.theta
+        g = torch.empty_like(theta)
+        with _nvq.device_guard(theta.device):
+            _nvq.ewc_penalty_grad(theta, ctx.star, ctx.fisher, ctx.lam, scale, g, False)
+        if net is not None:
+            views = net._bucket_views(g)
+            grads = [views[n] for n in net._param_names]
+        else:
+            grads, off = [], 0
+            for shp in ctx.shapes:
+                n = int(torch.Size(shp).numel())
+                grads.append(g[off:off + n].view(shp))
+                off += n
+        return (None, None, None, None) + tuple(grads)
 
 
 class EWC:
@@ -72,14 +159,21 @@ class EWC:
         self.task_fisher: Dict[int, Dict[str, torch.Tensor]] = {}
         self.task_optpar: Dict[int, Dict[str, torch.Tensor]] = {}
         self.num_tasks = 0
-        # flat buckets behind the dicts above (the dict entries are views into them)
-        self._flat: Dict[object, "tuple[torch.Tensor, torch.Tensor, List[str]]"] = {}
+        # flat buckets behind the dicts above (the dict entries are views into them):
+        # key ('online' | task id) -> [(segment, fisher_flat, optpar_flat)]
+        self._flat: Dict[object, "List[tuple]"] = {}
+        self._segs: "Optional[List[_Segment]]" = None
 
     # ------------------------------------------------------------------ helpers
     def _get_params(self) -> Iterator[tuple]:
         for name, param in self.model.named_parameters():
             if param.requires_grad:
                 yield name, param
+
+    def _segments(self) -> "List[_Segment]":
+        if self._segs is None:
+            self._segs = segments_of(self.model)
+        return self._segs
 
     def _device(self) -> torch.device:
         dev = next(self.model.parameters()).device
@@ -94,70 +188,111 @@ class EWC:
                        empirical: bool = True) -> Dict[str, torch.Tensor]:
         """Diagonal empirical Fisher exactly as the reference defines it (ewc.py:73-149): eval mode,
         per batch zero_grad -> forward -> batch-mean MSE -> backward -> fisher += grad**2, finally
-        divided by the number of samples seen (so it depends on the loader's batch size)."""
+        divided by the number of samples seen (so it depends on the loader's batch size).
+
+        Data parallel: every rank squares ITS OWN batch gradients - the gradient all-reduce hook of
+        ``nerve_cl.parallel`` is switched off for the duration - and the Fisher buckets and the sample count are summed
+        over the ranks in one all-reduce at the end, so the result equals the single-process Fisher over the union of
+        the ranks' batches.  No collective runs inside the loop, so ranks may see different batch counts."""
         dev = self._device()
-        named = list(self._get_params())
-        flat = torch.zeros(sum(p.numel() for _, p in named), dtype=torch.float32, device=dev)
+        segs = self._segments()
+        flats = [torch.zeros(sg.numel(), dtype=torch.float32, device=dev) for sg in segs]
+        nets = [m for m in self.model.modules() if isinstance(m, BucketedNet)]
+        hooks = [m._grad_bucket_hook for m in nets]
+        for m in nets:
+            m._grad_bucket_hook = None
         self.model.eval()
         seen = 0
-        for batch in dataloader:
-            if num_samples is not None and seen >= num_samples:
-                break
-            if isinstance(batch, (tuple, list)):
-                inputs = batch[0]
-                targets = batch[1] if len(batch) > 1 else None
-            else:
-                inputs, targets = batch, None
-            inputs = inputs.to(dev)
-            self.model.zero_grad()
-            outputs = self.model(inputs)
-            if empirical and targets is not None:
-                loss = nn.functional.mse_loss(outputs, targets.to(dev))
-            else:
-                loss = -0.5 * (outputs ** 2).sum() if outputs.dim() > 1 else outputs.sum()
-            loss.backward()
-            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1)
-                           for _, p in named])
-            _nvq.fisher_accumulate(g, flat)
-            seen += inputs.size(0)
+        try:
+            for batch in dataloader:
+                if num_samples is not None and seen >= num_samples:
+                    break
+                if isinstance(batch, (tuple, list)):
+                    inputs = batch[0]
+                    targets = batch[1] if len(batch) > 1 else None
+                else:
+                    inputs, targets = batch, None
+                inputs = inputs.to(dev)
+                self.model.zero_grad()
+                for m in nets:
+                    m._last_grad_bucket = None
+                outputs = self.model(inputs)
+                if empirical and targets is not None:
+                    loss = nn.functional.mse_loss(outputs, targets.to(dev))
+                else:
+                    loss = -0.5 * (outputs ** 2).sum() if outputs.dim() > 1 else outputs.sum()
+                loss.backward()
+                with _nvq.device_guard(dev):
+                    for sg, flat in zip(segs, flats):
+                        g = sg.grads()
+                        if g is not None:
+                            _nvq.fisher_accumulate(g, flat)
+                seen += inputs.size(0)
+        finally:
+            for m, h in zip(nets, hooks):
+                m._grad_bucket_hook = h
         if parallel.world_size(self.process_group) > 1:
-            parallel.allreduce_sum_(flat, self.process_group)
-            cnt = torch.tensor([float(seen)], device=dev)
-            parallel.allreduce_sum_(cnt, self.process_group)
-            seen = int(cnt.item())
-        flat /= max(seen, 1)
-        self._last_fisher_flat = flat
-        return _flat_views(flat, named)
+            packed = torch.cat(flats + [torch.tensor([float(seen)], device=dev)])
+            parallel.allreduce_sum_(packed, self.process_group)
+            off = 0
+            for flat in flats:
+                flat.copy_(packed[off:off + flat.numel()])
+                off += flat.numel()
+            seen = int(round(packed[off].item()))
+        for flat in flats:
+            flat /= max(seen, 1)
+        self._last_fisher_flats = flats
+        out: Dict[str, torch.Tensor] = {}
+        for sg, flat in zip(segs, flats):
+            out.update(sg.views(flat))
+        return {n: out[n] for n, _ in self._get_params()}
 
     def register_task(self, task_id: int, dataloader, num_samples: Optional[int] = None) -> None:
         fisher = self.compute_fisher(dataloader, num_samples)
-        f_flat = self._last_fisher_flat
-        named = list(self._get_params())
-        names = [n for n, _ in named]
-        o_flat = torch.cat([p.detach().reshape(-1) for _, p in named])
-        optpar = _flat_views(o_flat, named)
+        segs, f_flats = self._segments(), self._last_fisher_flats
+        o_flats = [sg.theta().clone() for sg in segs]
+        optpar: Dict[str, torch.Tensor] = {}
+        for sg, o in zip(segs, o_flats):
+            optpar.update(sg.views(o))
+        optpar = {n: optpar[n] for n, _ in self._get_params()}
         if self.mode == "separate":
             self.task_fisher[task_id] = fisher
             self.task_optpar[task_id] = optpar
-            self._flat[task_id] = (f_flat, o_flat, names)
+            self._flat[task_id] = list(zip(segs, f_flats, o_flats))
         elif self.mode == "online":
             if len(self.fisher_dict) == 0:
                 self.fisher_dict = fisher
             else:
-                old = self._flat["online"][0]
-                merged = self.decay * old + (1 - self.decay) * f_flat
-                self.fisher_dict = _flat_views(merged, named)
-                f_flat = merged
+                self._ensure_flat("online")                       # e.g. right after load_state_dict
+                merged = [self.decay * old + (1 - self.decay) * new
+                          for (_, old, _), new in zip(self._flat["online"], f_flats)]
+                fd: Dict[str, torch.Tensor] = {}
+                for sg, m in zip(segs, merged):
+                    fd.update(sg.views(m))
+                self.fisher_dict = {n: fd[n] for n, _ in self._get_params()}
+                f_flats = merged
             self.optpar_dict = optpar
-            self._flat["online"] = (f_flat, o_flat, names)
+            self._flat["online"] = list(zip(segs, f_flats, o_flats))
         self.num_tasks += 1
 
     # ------------------------------------------------------------------ penalty
     def _penalty_one(self, model: nn.Module, key) -> torch.Tensor:
-        f_flat, o_flat, names = self._flat[key]
+        total = None
+        if model is self.model:
+            for sg, f_flat, o_flat in self._flat[key]:
+                term = _PenaltyFn.apply(sg, self.ewc_lambda, o_flat, f_flat, *[p for _, p in sg.named])
+                total = term if total is None else total + term
+            return total
+        # another module with the same parameter names (reference signature penalty(model)): plain concatenation
         have = dict(model.named_parameters())
-        params = [have[n] for n in names]
-        return _PenaltyFn.apply(self.ewc_lambda, o_flat, f_flat, *params)
+        for sg, f_flat, o_flat in self._flat[key]:
+            fv, ov = sg.views(f_flat), sg.views(o_flat)
+            params = [have[n] for n in sg.names]
+            f = torch.cat([fv[n].reshape(-1) for n in sg.names])
+            o = torch.cat([ov[n].reshape(-1) for n in sg.names])
+            term = _PenaltyFn.apply(None, self.ewc_lambda, o, f, *params)
+            total = term if total is None else total + term
+        return total
 
     def penalty(self, model: Optional[nn.Module] = None):
         """lambda/2 * sum_i F_i (theta_i - theta*_i)^2 ; python 0.0 before any task is registered
@@ -181,10 +316,17 @@ class EWC:
             return
         dev = self._device()
         fd, od = (self.fisher_dict, self.optpar_dict) if key == "online" else (self.task_fisher[key], self.task_optpar[key])
-        names = [n for n, _ in self.model.named_parameters() if n in fd]
-        f_flat = torch.cat([fd[n].to(dev, torch.float32).reshape(-1) for n in names])
-        o_flat = torch.cat([od[n].to(dev, torch.float32).reshape(-1) for n in names])
-        self._flat[key] = (f_flat, o_flat, names)
+        entry = []
+        for sg in self._segments():
+            f_flat = torch.zeros(sg.numel(), dtype=torch.float32, device=dev)
+            o_flat = torch.zeros(sg.numel(), dtype=torch.float32, device=dev)
+            fv, ov = sg.views(f_flat), sg.views(o_flat)
+            for n in sg.names:
+                if n in fd:
+                    fv[n].copy_(fd[n].to(dev, torch.float32))
+                    ov[n].copy_(od[n].to(dev, torch.float32))
+            entry.append((sg, f_flat, o_flat))
+        self._flat[key] = entry
 
     # ------------------------------------------------------------------ bookkeeping
     def get_importance_stats(self) -> Dict[str, dict]:
@@ -272,4 +414,4 @@ class SynapticIntelligence:
         self._set_p_old(theta)
 
     def penalty(self) -> torch.Tensor:
-        return _PenaltyFn.apply(2.0 * self.si_lambda, self._p_old, self._omega, *[p for _, p in self._named])
+        return _PenaltyFn.apply(None, 2.0 * self.si_lambda, self._p_old, self._omega, *[p for _, p in self._named])

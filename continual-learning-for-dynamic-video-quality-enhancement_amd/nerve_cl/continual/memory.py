@@ -14,10 +14,19 @@ import torch
 
 
 class EpisodicMemory:
-    def __init__(self, capacity: int = 1000, strategy: str = "reservoir", seed: Optional[int] = None):
-        if strategy not in ("reservoir", "stratified", "fifo", "importance", "diversity"):
+    """Bounded CPU-side sample store.  Semantics follow the reference (memory.py:38-349): eviction per strategy once full,
+    ``sample(batch_size, content_type, device)`` draws WITHOUT replacement and never more than is stored, and
+    ``save`` / ``load`` use the reference's on-disk dictionary {'buffer': [(lr, hr, metadata, importance)], 'total_seen',
+    'strategy', 'capacity'} so files written by either side load on the other (tensors, dicts and floats only:
+    ``weights_only=True`` suffices)."""
+
+    STRATEGIES = ("uniform", "reservoir", "stratified", "fifo", "importance", "diversity")
+
+    def __init__(self, capacity: int = 1000, strategy: str = "reservoir", diversity_weight: float = 0.3,
+                 seed: Optional[int] = None):
+        if strategy not in self.STRATEGIES:
             raise ValueError(f"unknown strategy {strategy!r}")
-        self.capacity, self.strategy = capacity, strategy
+        self.capacity, self.strategy, self.diversity_weight = capacity, strategy, diversity_weight
         self._items: List[dict] = []
         self._seen = 0
         self._rng = random.Random(seed)
@@ -25,56 +34,86 @@ class EpisodicMemory:
     def __len__(self) -> int:
         return len(self._items)
 
+    @property
+    def total_seen(self) -> int:
+        return self._seen
+
+    @staticmethod
+    def _ctype(item: dict) -> str:
+        return item["meta"].get("content_type", "unknown")
+
     def _by_type(self) -> Dict[str, List[int]]:
         groups: Dict[str, List[int]] = defaultdict(list)
         for i, it in enumerate(self._items):
-            groups[it["meta"].get("content_type", "unknown")].append(i)
+            groups[self._ctype(it)].append(i)
         return groups
+
+    def _reservoir(self, item: dict) -> bool:
+        """Keep the newcomer with probability capacity / seen, in a uniformly chosen slot (reference :133-148)."""
+        if self._rng.random() < self.capacity / self._seen:
+            self._items[self._rng.randrange(self.capacity)] = item
+            return True
+        return False
 
     def store(self, lr: torch.Tensor, hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
               importance: float = 1.0) -> bool:
-        item = {"lr": lr.detach().cpu(), "hr": hr.detach().cpu(), "meta": dict(metadata or {}),
-                "importance": float(importance)}
+        item = {"lr": lr.detach().cpu(), "hr": hr.detach().cpu(), "meta": metadata or {},
+                "importance": float(importance), "access_count": 0}
         self._seen += 1
         if len(self._items) < self.capacity:
             self._items.append(item)
             return True
-        if self.strategy == "fifo":
-            self._items.pop(0)
-            self._items.append(item)
-            return True
+        if self.strategy == "reservoir":
+            return self._reservoir(item)
         if self.strategy == "stratified":
-            # evict from the most populous content type so that types stay balanced
+            # a type that is not (yet) the largest one takes a slot from the largest; otherwise reservoir (reference :150-169)
             groups = self._by_type()
-            biggest = max(groups.values(), key=len)
-            own = groups.get(item["meta"].get("content_type", "unknown"), [])
-            victims = own if len(own) >= len(biggest) else biggest   # never grow the largest class
-            self._items[self._rng.choice(victims)] = item
-            return True
+            biggest = max(groups, key=lambda k: len(groups[k]))
+            if len(groups.get(self._ctype(item), [])) < len(groups[biggest]):
+                self._items[self._rng.choice(groups[biggest])] = item
+                return True
+            return self._reservoir(item)
         if self.strategy == "importance":
             j = min(range(len(self._items)), key=lambda k: self._items[k]["importance"])
-            if self._items[j]["importance"] <= item["importance"]:
+            if item["importance"] > self._items[j]["importance"]:
                 self._items[j] = item
                 return True
             return False
-        # reservoir (also the fallback for 'diversity')
-        j = self._rng.randrange(self._seen)
-        if j < self.capacity:
-            self._items[j] = item
-            return True
-        return False
+        if self.strategy == "diversity":
+            # replace the stored sample closest in mean colour if the newcomer is further than 0.1 from it (reference :186-211)
+            feats = torch.stack([it["lr"].mean(dim=(1, 2)) for it in self._items])
+            dist = torch.norm(feats - item["lr"].mean(dim=(1, 2)), dim=1)
+            j = int(dist.argmin())
+            if dist[j] > 0.1:
+                self._items[j] = item
+                return True
+            return False
+        self._items.pop(0)                                        # 'uniform' / 'fifo': first in, first out
+        self._items.append(item)
+        return True
 
-    def sample(self, batch_size: int, device: Optional[torch.device] = None, content_type: Optional[str] = None):
+    def _spread(self, batch_size: int) -> List[int]:
+        """batch_size indices split evenly over the content types, the first types taking the remainder (reference :287-305)."""
+        groups = self._by_type()
+        per, rem = divmod(batch_size, len(groups))
+        idx: List[int] = []
+        for members in groups.values():
+            n = min(per + (1 if rem > 0 else 0), len(members))
+            rem -= 1
+            idx.extend(self._rng.sample(members, n))
+        return idx[:batch_size]
+
+    def sample(self, batch_size: int = 32, content_type: Optional[str] = None, device: Optional[torch.device] = None):
         if not self._items:
-            raise ValueError("memory is empty")
-        pool = list(range(len(self._items)))
-        if content_type is not None:
-            pool = [i for i in pool if self._items[i]["meta"].get("content_type") == content_type] or pool
-        if self.strategy == "stratified" and content_type is None:
-            groups = list(self._by_type().values())
-            idx = [self._rng.choice(groups[k % len(groups)]) for k in range(batch_size)]
+            raise ValueError("Memory buffer is empty")
+        batch_size = min(batch_size, len(self._items))
+        groups = self._by_type()
+        if content_type is not None and content_type in groups:
+            idx = self._rng.sample(groups[content_type], min(batch_size, len(groups[content_type])))
         else:
-            idx = [self._rng.choice(pool) for _ in range(batch_size)]
+            idx = self._spread(batch_size)
+        for i in idx:
+            self._items[i]["access_count"] += 1
         lr = torch.stack([self._items[i]["lr"] for i in idx])
         hr = torch.stack([self._items[i]["hr"] for i in idx])
         if device is not None:
@@ -82,19 +121,22 @@ class EpisodicMemory:
         return lr, hr, [self._items[i]["meta"] for i in idx]
 
     def get_stats(self) -> Dict[str, Any]:
-        return {"size": len(self), "capacity": self.capacity, "total_seen": self._seen,
-                "content_distribution": {k: len(v) for k, v in self._by_type().items()}}
+        return {"size": len(self), "capacity": self.capacity, "utilization": len(self) / self.capacity,
+                "total_seen": self._seen, "content_distribution": {k: len(v) for k, v in self._by_type().items()},
+                "strategy": self.strategy}
 
     def clear(self) -> None:
         self._items, self._seen = [], 0
 
     def save(self, path: str) -> None:
-        torch.save({"capacity": self.capacity, "strategy": self.strategy, "seen": self._seen,
-                    "items": self._items}, path)
+        torch.save({"buffer": [(it["lr"], it["hr"], it["meta"], it["importance"]) for it in self._items],
+                    "total_seen": self._seen, "strategy": self.strategy, "capacity": self.capacity}, path)
 
     def load(self, path: str) -> None:
-        blob = torch.load(path, weights_only=False)   # a file this class wrote itself
-        self.capacity, self.strategy, self._seen, self._items = blob["capacity"], blob["strategy"], blob["seen"], blob["items"]
+        blob = torch.load(path, weights_only=True)
+        self._items = [{"lr": lr, "hr": hr, "meta": meta, "importance": float(imp), "access_count": 0}
+                       for lr, hr, meta, imp in blob["buffer"]]
+        self._seen = blob["total_seen"]
 
 
 
@@ -117,7 +159,7 @@ class StreamingEpisodicMemory(EpisodicMemory):
     def sample(self, batch_size: int = 32, content_type: Optional[str] = None, device: Optional[torch.device] = None,
                use_recency: bool = True):
         if not use_recency:
-            return super().sample(batch_size, device=device, content_type=content_type)
+            return super().sample(batch_size, content_type=content_type, device=device)
         if not self._items:
             raise ValueError("memory is empty")
         batch_size = min(batch_size, len(self._items))

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from nerve_cl import _engine, _graphs, _nvq
+from nerve_cl._bucket import BucketedNet
 from nerve_cl.models.layers import (
     CBAM,
     DepthwiseSeparableConv,
@@ -84,6 +85,8 @@ class _SRFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[3:])
         ctx.net = net
         ctx.graph = ctx.token = None
+        if need_grad:
+            net._awaiting_backward = True
         if net._graphs_wanted(frames) and not want_inter:
             hit = net._step_graphs.forward(net, frames, need_grad, act)
             if hit is not None:
@@ -108,19 +111,18 @@ class _SRFunction(torch.autograd.Function):
                 raise RuntimeError("SuperResolutionNet backward called without saved forward state (a second backward through "
                                    "the same forward needs net.retain_backward_state = True, the analogue of retain_graph)")
             flat, views = net._new_grad_bucket()
-            _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
+            with torch.cuda.device(dout.device):
+                _engine.backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
             # A custom Function cannot see retain_graph, and the state of a 540p step is tens of GB that must not outlive
             # the backward (autograd frees its own saved tensors here too), so it is dropped unless the module asks to keep it.
             if not getattr(net, "retain_backward_state", False):
                 ctx.sv = None
-        hook = net._grad_bucket_hook
-        if hook is not None:
-            hook(flat)           # data-parallel all-reduce of the whole bucket (nerve_cl.parallel)
-        net._last_grad_bucket = flat
+        # data-parallel all-reduce of the whole bucket (nerve_cl.parallel), then the deferred EWC penalty gradient
+        net._finish_bucket(flat)
         return (None, None, None) + tuple(views[n] for n in names)
 
 
-class SuperResolutionNet(nn.Module):
+class SuperResolutionNet(BucketedNet):
     """Temporal super-resolution network (reference :256-431), MI355X-native.
 
     Args (same as the reference):
@@ -156,10 +158,8 @@ class SuperResolutionNet(nn.Module):
         bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
         self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
         self.bf16_activations = bf16 and os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
-        self._param_names: List[str] = [n for n, _ in self.named_parameters()]
-        self._grad_bucket_hook = None
+        self._init_bucket()
         self._last_intermediates = None
-        self._last_grad_bucket = None
         # HIP-graph replay of the step (nerve_cl/_graphs.py): True / False / "auto" = only for small frame sizes.  Off by
         # default: measured on MI355X it frees the host thread but does not shorten the step (see _graphs.py).
         # NVQ_GRAPH=1|0|auto sets the default for unmodified caller scripts.
@@ -173,31 +173,6 @@ class SuperResolutionNet(nn.Module):
         if self.use_hip_graphs == "auto":
             return frames.numel() // frames.shape[2] <= self.GRAPH_AUTO_MAX_PIXELS
         return bool(self.use_hip_graphs)
-
-    # ------------------------------------------------------------------ plumbing
-    def _tensor_dict(self) -> Dict[str, torch.Tensor]:
-        d = {n: p.data for n, p in self.named_parameters()}
-        d.update({n: b for n, b in self.named_buffers()})
-        return d
-
-    def _bucket_layout(self) -> "Tuple[Dict[str, Tuple[int, int]], int]":
-        """{name: (offset, numel)} with 16-byte aligned offsets, total floats."""
-        lay, off = {}, 0
-        for n, p in self.named_parameters():
-            lay[n] = (off, p.numel())
-            off += (p.numel() + 3) // 4 * 4
-        return lay, off
-
-    def _bucket_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
-        lay, _ = self._bucket_layout()
-        shapes = {n: p.shape for n, p in self.named_parameters()}
-        return {n: flat[o:o + k].view(shapes[n]) for n, (o, k) in lay.items()}
-
-    def _new_grad_bucket(self):
-        _, total = self._bucket_layout()
-        dev = next(self.parameters()).device
-        flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        return flat, self._bucket_views(flat)
 
     # ------------------------------------------------------------------ reference API
     def forward(self, lr_frames: torch.Tensor, return_intermediate: bool = False):
@@ -213,7 +188,8 @@ class SuperResolutionNet(nn.Module):
             raise RuntimeError("frames must be at least 2x2 (grid_sample normalisation divides by size-1)")
         frames = lr_frames.detach().to(torch.float32).contiguous()
         params = [p for _, p in self.named_parameters()]
-        out = _SRFunction.apply(self, frames, bool(return_intermediate), *params)
+        with torch.cuda.device(frames.device):      # the kernels launch on the CURRENT device's stream
+            out = _SRFunction.apply(self, frames, bool(return_intermediate), *params)
         if return_intermediate:
             inter, self._last_intermediates = self._last_intermediates, None
             return out, inter
@@ -231,8 +207,9 @@ class SuperResolutionNet(nn.Module):
         if self.training:
             raise RuntimeError("extract_features is an eval-mode (running BatchNorm statistics) inference path")
         _nvq.require_device(frames, "frames")
-        return _engine.extract_features(self._tensor_dict(), frames.detach().to(torch.float32).contiguous(), self._F,
-                                        self.math_mode, self._act_dtype())
+        with torch.cuda.device(frames.device):
+            return _engine.extract_features(self._tensor_dict(), frames.detach().to(torch.float32).contiguous(), self._F,
+                                            self.math_mode, self._act_dtype())
 
     @torch.no_grad()
     def forward_cached(self, lr_frames: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
@@ -242,9 +219,10 @@ class SuperResolutionNet(nn.Module):
         B, T, C, H, W = lr_frames.shape
         if T != self.num_frames:
             raise RuntimeError(f"expected {self.num_frames} frames, got {T}")
-        out, _ = _engine.forward(self._tensor_dict(), lr_frames.detach().to(torch.float32).contiguous(), self._F, self._NB,
-                                 self.scale_factor, False, self.math_mode, self._act_dtype(),
-                                 features=features.contiguous())
+        with torch.cuda.device(lr_frames.device):
+            out, _ = _engine.forward(self._tensor_dict(), lr_frames.detach().to(torch.float32).contiguous(), self._F,
+                                     self._NB, self.scale_factor, False, self.math_mode, self._act_dtype(),
+                                     features=features.contiguous())
         return out
 
     def forward_single(self, lr_frame: torch.Tensor) -> torch.Tensor:
@@ -273,6 +251,8 @@ class _LightFunction(torch.autograd.Function):
         out, sv = _engine.light_forward(net._tensor_dict(), x, net.scale_factor, net.training, net.math_mode, act)
         ctx.net = net
         ctx.sv = sv if any(ctx.needs_input_grad[2:]) else None
+        if ctx.sv is not None:
+            net._awaiting_backward = True
         return out
 
     @staticmethod
@@ -281,16 +261,15 @@ class _LightFunction(torch.autograd.Function):
         if sv is None:
             raise RuntimeError("LightweightSuperResolution backward called without saved forward state")
         flat, views = net._new_grad_bucket()
-        _engine.light_backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
+        with torch.cuda.device(dout.device):
+            _engine.light_backward(net._tensor_dict(), sv, dout.contiguous().float(), views)
         if not getattr(net, "retain_backward_state", False):
             ctx.sv = None
-        if net._grad_bucket_hook is not None:
-            net._grad_bucket_hook(flat)
-        net._last_grad_bucket = flat
+        net._finish_bucket(flat)
         return (None, None) + tuple(views[n] for n in net._param_names)
 
 
-class LightweightSuperResolution(nn.Module):
+class LightweightSuperResolution(BucketedNet):
     """Single-frame variant (reference :434-470): conv3x3+ReLU, 4 depthwise-separable blocks (32 features),
     conv3x3 -> PixelShuffle, + bicubic(x), clamp.  ``state_dict`` keys are the reference's (``net.<i>.*``)."""
 
@@ -306,14 +285,7 @@ class LightweightSuperResolution(nn.Module):
         bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
         self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
         self.bf16_activations = bf16 and os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
-        self._param_names: List[str] = [n for n, _ in self.named_parameters()]
-        self._grad_bucket_hook = None
-        self._last_grad_bucket = None
-
-    _tensor_dict = SuperResolutionNet._tensor_dict
-    _bucket_layout = SuperResolutionNet._bucket_layout
-    _bucket_views = SuperResolutionNet._bucket_views
-    _new_grad_bucket = SuperResolutionNet._new_grad_bucket
+        self._init_bucket()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> (B,3,H*s,W*s)."""
@@ -322,4 +294,5 @@ class LightweightSuperResolution(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected (B,3,H,W), got {tuple(x.shape)}")
         params = [p for _, p in self.named_parameters()]
-        return _LightFunction.apply(self, x.detach().to(torch.float32).contiguous(), *params)
+        with torch.cuda.device(x.device):
+            return _LightFunction.apply(self, x.detach().to(torch.float32).contiguous(), *params)

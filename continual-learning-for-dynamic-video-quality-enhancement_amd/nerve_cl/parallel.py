@@ -79,17 +79,28 @@ def unflatten_into_(flat: torch.Tensor, tensors: Iterable[torch.Tensor]) -> None
 
 
 def enable_data_parallel(module: torch.nn.Module, group=None, broadcast: bool = True) -> torch.nn.Module:
-    """Turn on gradient all-reduce for every SuperResolutionNet inside `module`.
+    """Turn on gradient all-reduce for every bucketed network (SuperResolutionNet, LightweightSuperResolution,
+    FrameRecoveryNet) inside `module`.
 
     After this call ``loss.backward()`` leaves rank-averaged gradients in ``.grad`` exactly
-    where a single-process run would leave them, so the reference training loops need no change."""
-    from nerve_cl.models.super_resolution import SuperResolutionNet
+    where a single-process run would leave them, so the reference training loops need no change.
+    (``EWC.compute_fisher`` switches the hook off while it runs: the Fisher needs per-rank gradients.)"""
+    from nerve_cl._bucket import BucketedNet
     if broadcast:
         broadcast_state_(module, 0, group)
     for m in module.modules():
-        if isinstance(m, SuperResolutionNet):
+        if isinstance(m, BucketedNet):
             m._grad_bucket_hook = (lambda flat, g=group: allreduce_mean_(flat, g))
     return module
+
+
+def allreduce_scalars(values, group=None, device=None) -> "list[float]":
+    """Sum a few python floats over the ranks in one collective (rank-uniform decisions in the training scripts)."""
+    if world_size(group) <= 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()
 
 
 def average_bn_buffers_(module: torch.nn.Module, group=None) -> None:
@@ -98,7 +109,10 @@ def average_bn_buffers_(module: torch.nn.Module, group=None) -> None:
     w = world_size(group)
     if w <= 1:
         return
-    for n, b in module.named_buffers():
-        if b.dtype.is_floating_point:
-            dist.all_reduce(b, group=group)
-            b.div_(w)
+    bufs = [b for _, b in module.named_buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    flat = flatten([b.detach().float() for b in bufs])       # one collective for all of them
+    dist.all_reduce(flat, group=group)
+    flat.div_(w)
+    unflatten_into_(flat, [b.data for b in bufs])

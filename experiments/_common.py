@@ -29,6 +29,8 @@ def pick_device():
 
 
 def shard(n: int, rank: int, world: int) -> slice:
-    """Contiguous shard of a dataset of n samples for this rank."""
-    per = (n + world - 1) // world
-    return slice(rank * per, min(n, (rank + 1) * per))
+    """Contiguous shard of a dataset of n samples for this rank.  Every rank gets the SAME number of samples (the
+    remainder n % world is dropped): the gradient all-reduce runs once per training batch inside backward, so ranks with
+    different batch counts would wait for each other forever."""
+    per = n // world
+    return slice(rank * per, (rank + 1) * per)

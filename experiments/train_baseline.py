@@ -70,8 +70,11 @@ def train(args) -> None:
                 out = model(as_clip(lr))
                 val_loss += criterion(out, hr).item()
                 val_psnr += compute_psnr(out, hr)
-        val_loss /= max(len(val_loader), 1)
-        val_psnr /= max(len(val_loader), 1)
+        # rank-uniform validation numbers (each rank validated its shard): every rank must take the same branch below,
+        # because the branch contains collectives
+        val_loss, val_psnr, nval = parallel.allreduce_scalars([val_loss, val_psnr, len(val_loader)], device=device)
+        val_loss /= max(nval, 1)
+        val_psnr /= max(nval, 1)
         scheduler.step()
         say(f"Epoch {epoch + 1:3d}/{args.epochs} | Train Loss: {running:.4f} | Val Loss: {val_loss:.4f} | "
             f"Val PSNR: {val_psnr:.2f} dB | Time: {time.time() - t_start:.1f}s")

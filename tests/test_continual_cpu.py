@@ -23,7 +23,23 @@ def test_memory_store_sample_capacity_and_stratification():
         for _ in range(20):
             m3.store(torch.randn(3, 8, 8), torch.randn(3, 16, 16), {"content_type": ct})
     dist = m3.get_stats()["content_distribution"]
-    assert len(dist) == 3 and max(dist.values()) - min(dist.values()) <= 1 and sum(dist.values()) == 30
+    # reference semantics (memory.py:150-169): an under-represented type takes slots from the largest one, a type that
+    # has caught up falls back to reservoir replacement - balanced up to the reservoir's noise, never starved
+    assert len(dist) == 3 and min(dist.values()) >= 6 and sum(dist.values()) == 30
+    # on-disk format of the reference (memory.py:325-349) and draws without replacement, capped at what is stored
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        m3.save(os.path.join(d, "mem.pt"))
+        blob = torch.load(os.path.join(d, "mem.pt"), weights_only=True)
+        assert set(blob) == {"buffer", "total_seen", "strategy", "capacity"} and len(blob["buffer"][0]) == 4
+        m4 = EpisodicMemory(capacity=30, strategy="stratified")
+        m4.load(os.path.join(d, "mem.pt"))
+        assert len(m4) == 30 and m4.get_stats()["content_distribution"] == dist and m4.total_seen == 60
+    lr, hr, meta = m4.sample(64)
+    assert 24 <= lr.shape[0] <= 30            # per-type quotas are capped by what each type holds (reference :287-305)
+    lr, hr, meta = m4.sample(4, "sports")
+    assert all(mm["content_type"] == "sports" for mm in meta)
+    assert set(m4.get_stats()) == {"size", "capacity", "utilization", "total_seen", "content_distribution", "strategy"}
 
 
 def test_fomaml_adapt_and_distillation_on_plain_modules():
