@@ -32,19 +32,38 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak 
 PEAK_HBM_GBS = 8000.0
 
 
-def pmc_traffic(kernel: str, batch: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE collected
-    in two separate passes of this script at the default batch, corrected as MI355X_MICROARCH.md prescribes).
-    bench.py cannot collect PMC counters itself; returns None when no matching summary exists."""
-    path = os.path.join(REPO, "profiles", "r01_v5_traffic_pmc.json")
-    if batch != 8 or not os.path.exists(path):
-        return None
-    try:
-        blob = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    v = blob.get(kernel)
-    return v["hbm_bytes_per_launch"] / 1e9 if v else None
+def sources_sha() -> str:
+    """Fingerprint of what determines the kernels' HBM traffic: every HIP source / header and the launch schedule.
+    tools/pmc_traffic.py stores it in the PMC summary it writes; a summary taken at other sources is not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")))
+    files += [os.path.join(PKG, "nerve_cl", "_engine.py"), os.path.join(PKG, "nerve_cl", "_nvq.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel: str, batch: int, workload: str):
+    """(GB per launch, file name) of `kernel` from a committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE collected
+    in two separate passes of this script, corrected as MI355X_MICROARCH.md prescribes) - but only from a summary whose
+    recorded source fingerprint, workload and batch are THIS run's; (None, None) otherwise.  bench.py cannot collect PMC
+    counters itself."""
+    import glob
+    sha = sources_sha()
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic_pmc.json")), reverse=True):
+        try:
+            blob = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if blob.get("sources_sha") != sha or blob.get("workload") != workload or blob.get("batch") != batch:
+            continue
+        v = blob.get("kernels", {}).get(kernel)
+        if v:
+            return v["hbm_bytes_per_launch"] / 1e9, os.path.basename(path)
+    return None, None
 
 
 def host_cores() -> int:
@@ -59,15 +78,33 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(args, cfg):
+def cpu_baseline(args, cfg, parity_probe=None):
     """Time the oracle's training step on the host cores on a BOUNDED sample: one clip at 1/16 of
     the pixels (135x240) and scale the rate by the pixel ratio.  The CPU path is super-linear in
     pixels (1.05 s at 135x240, 16.5 s at 270x480, ~75 GB of autograd state at
-    540p), so this extrapolation flatters the CPU; it is a reported baseline, not the target."""
+    540p), so this extrapolation flatters the CPU; it is a reported baseline, not the target.
+
+    The same leg is the run's parity check ("PSNR vs ref", the second half of BASELINE.json's metric): parity_probe =
+    (state_dict, clips, targets, GPU output, GPU loss) of a small crop that went through the benchmarked mode; the oracle
+    evaluates it in fp32 and PSNR (formula of experiments/train_baseline.py:27-32) / relative loss are reported."""
     from oracle import sr_oracle
     from nerve_cl.models import SuperResolutionNet
     cores = host_cores()
     torch.set_num_threads(cores)
+    parity = None
+    if parity_probe is not None:
+        sd, xs, ys, out_gpu, loss_gpu = parity_probe
+        ora = sr_oracle.OracleSR(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"])
+        ora.load_named(sd)
+        ora.train()
+        with torch.no_grad():
+            out_cpu = ora(xs)
+            loss_cpu = F.mse_loss(out_cpu, ys).item()
+        parity = {"psnr_vs_oracle_db": sr_oracle.compute_psnr(out_gpu, out_cpu),
+                  "loss_rel_vs_oracle": abs(loss_gpu - loss_cpu) / loss_cpu,
+                  "max_abs_err": (out_gpu - out_cpu).abs().max().item(),
+                  "probe": f"{xs.shape[0]} clips of {xs.shape[-2]}x{xs.shape[-1]} cropped from the benchmark batch, the "
+                           f"benchmarked weights and mode (train-mode BatchNorm) vs the fp32 CPU oracle"}
     Hc, Wc = cfg["H"] // 4, cfg["W"] // 4
     torch.manual_seed(0)
     ora = sr_oracle.OracleSR(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"])
@@ -92,6 +129,44 @@ def cpu_baseline(args, cfg):
     timed = sorted(times[1:])
     t = timed[len(timed) // 2]
     ratio = (cfg["H"] * cfg["W"]) / (Hc * Wc)
+    extra = {}
+    if not args.no_cpu_extras:
+        # the reference's own CPU-runnable case (BASELINE configs[0]: F=32, 4 blocks, B=16, 64x64) and the
+        # measured full-size INFERENCE forward beside the extrapolated training rate
+        try:
+            torch.manual_seed(0)
+            o1 = sr_oracle.OracleSR(3, 2, 32, 4, 1)
+            o1.load_named(SuperResolutionNet(3, 2, 32, 4, 1).state_dict())
+            o1.train()
+            op1 = torch.optim.AdamW(o1.parameters(), lr=1e-3, weight_decay=1e-5)
+            x1, y1 = torch.rand(16, 3, 3, 64, 64, generator=g), torch.rand(16, 3, 128, 128, generator=g)
+            ts = []
+            for i in range(3):
+                t0 = time.perf_counter()
+                op1.zero_grad()
+                F.mse_loss(o1(x1), y1).backward()
+                op1.step()
+                ts.append(time.perf_counter() - t0)
+                print(f"[bench] cpu cfg1 step {i}: {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+                if time.perf_counter() - budget_t0 > 90.0:
+                    break
+            if len(ts) > 1:
+                extra["cfg1_train_clips_per_s"] = 16.0 / min(ts[1:])
+                extra["cfg1_sample"] = (f"F=32, 4 blocks, T=3, B=16, 64x64 train step, best of {len(ts) - 1} after one "
+                                        f"warm-up: {min(ts[1:]):.2f} s")
+            if time.perf_counter() - budget_t0 < 100.0:
+                ora.eval()
+                xf = torch.rand(1, cfg["T"], 3, cfg["H"], cfg["W"], generator=g)
+                with torch.no_grad():
+                    t0 = time.perf_counter()
+                    ora(xf)
+                    tf = time.perf_counter() - t0
+                extra["full_size_inference_forward_s"] = tf
+                extra["full_size_inference_sample"] = (f"one eval-mode no-grad forward of one {cfg['H']}x{cfg['W']} clip "
+                                                       f"(first call at this shape, primitive creation included)")
+                print(f"[bench] cpu {cfg['H']}x{cfg['W']} inference forward: {tf:.2f} s", file=sys.stderr, flush=True)
+        except MemoryError:
+            pass
     return {
         "value": (1.0 / t) / ratio,
         "unit": "frames/s",
@@ -101,6 +176,8 @@ def cpu_baseline(args, cfg):
                   f"same net on one {Hc}x{Wc} clip = 1/{ratio:.0f} of the 540p pixels: {t:.2f} s/step; rate divided "
                   f"by {ratio:.0f} (flatters the CPU, whose cost grows faster than the pixel count); 1 warm-up "
                   f"step excluded",
+        "parity": parity,
+        **extra,
     }
 
 
@@ -123,11 +200,13 @@ def main():
                     help="with --math bf16: keep the conv-internal tensors in fp32 (default: bf16 storage)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-extras", action="store_true",
+                    help="skip the cfg1 CPU timing and the full-size CPU inference forward of the cpu_baseline leg")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape table of the conv launches to stderr")
     args = ap.parse_args()
 
-    from nerve_cl import _nvq, parallel
+    from nerve_cl import _nvq, ops, parallel
     from nerve_cl.models import SuperResolutionNet
 
     if args.backend != "nccl":
@@ -147,6 +226,12 @@ def main():
     cfg = dict(F=args.features, blocks=args.blocks, window=args.window, T=2 * args.window + 1,
                scale=args.scale, H=args.height, W=args.width)
 
+    is_cfg2 = (cfg["scale"], cfg["F"], cfg["blocks"], cfg["T"], cfg["H"], cfg["W"]) == (2, 64, 8, 3, 540, 960)
+    is_cfg4 = (cfg["scale"], cfg["F"], cfg["blocks"], cfg["T"], cfg["H"], cfg["W"]) == (4, 64, 8, 5, 270, 480)
+    tag = "cfg2" if is_cfg2 else "cfg4 (SR part)" if is_cfg4 else "custom"
+    workload = (f"{tag}: SuperResolutionNet(scale={cfg['scale']}, feat={cfg['F']}, blocks={cfg['blocks']}, T={cfg['T']}) "
+                f"train step on {cfg['H']}x{cfg['W']} -> {cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips")
+
     torch.manual_seed(0)
     net = SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).to(dev).train()
     net.math_mode = _nvq.MATH_BF16 if args.math == "bf16" else _nvq.MATH_F32
@@ -161,7 +246,7 @@ def main():
 
     def step():
         opt.zero_grad()
-        loss = F.mse_loss(net(x), y)
+        loss = ops.mse_loss(net(x), y)          # nn.MSELoss of the reference loop as libnvq kernels
         loss.backward()
         opt.step()
         return loss
@@ -215,9 +300,10 @@ def main():
             name, d = max(kernels.items(), key=lambda kv: kv[1]["ms_total"])
             tflops = d["flops"] / (d["ms_total"] * 1e-3) / 1e12
             gbs = d["bytes"] / (d["ms_total"] * 1e-3) / 1e9
-            traffic = pmc_traffic(name, B) if args.math == "bf16" and not args.fp32_acts else None
-            common = {"traffic": traffic, "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
-                                                          "profiles/r01_v5_traffic_pmc.json)" if traffic else None,
+            traffic, tfile = pmc_traffic(name, B, workload) if args.math == "bf16" and not args.fp32_acts else (None, None)
+            common = {"traffic": traffic, "traffic_unit": f"GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
+                                                          f"profiles/{tfile}, same sources fingerprint {sources_sha()})"
+                      if traffic else None,
                       "algorithmic_gb_per_launch": d["bytes"] / d["launches"] / 1e9,
                       "kernel": name, "launches": d["launches"],
                       "avg_launch_ms": d["ms_total"] / d["launches"],
@@ -249,14 +335,25 @@ def main():
             sec = d["ms_total"] * 1e-3
             print("%-24s %-34s %5d %9.3f %9.1f %9.0f" % (label, shape, d["launches"] // args.steps,
                   d["ms_total"] / args.steps, d["flops"] / sec / 1e12, d["bytes"] / sec / 1e9), file=sys.stderr)
+    # "PSNR vs ref" (second half of BASELINE.json's metric): a crop of the benchmark batch through the benchmarked mode,
+    # checked against the fp32 CPU oracle inside the cpu_baseline leg
+    parity_probe = None
+    if world == 1 and not args.no_cpu_baseline:
+        hs, ws_ = min(cfg["H"], 64), min(cfg["W"], 96)
+        xs = x[:2, :, :, :hs, :ws_].contiguous()
+        ys = y[:2, :, :hs * cfg["scale"], :ws_ * cfg["scale"]].contiguous()
+        with torch.no_grad():
+            out_s = net(xs)
+            loss_s = ops.mse_loss(out_s, ys).item()
+        parity_probe = ({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, xs.cpu(), ys.cpu(),
+                        out_s.cpu(), loss_s)
     line = {
-        "metric": "train frames/sec (2x SR, T=3, 540p->1080p)",
+        "metric": "train frames/sec (2x SR, T=3, 540p->1080p)" if is_cfg2 else
+                  f"train frames/sec ({cfg['scale']}x SR, T={cfg['T']}, {cfg['H']}x{cfg['W']})",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"cfg2: SuperResolutionNet(scale={cfg['scale']}, feat={cfg['F']}, "
-                               f"blocks={cfg['blocks']}, T={cfg['T']}) train step on {cfg['H']}x{cfg['W']} -> "
-                               f"{cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips",
+        "config": {"workload": workload,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "lr_input_frames_per_s": value * cfg["T"], "final_loss": final_loss,
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
@@ -269,7 +366,11 @@ def main():
         line["kernel_ms_per_step"] = {k: round(v["ms_total"] / args.steps, 3) for k, v in
                                       sorted(kernels.items(), key=lambda kv: -kv[1]["ms_total"])}
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args, cfg)
+        line["cpu_baseline"] = cpu_baseline(args, cfg, parity_probe)
+        par = line["cpu_baseline"].get("parity")
+        if par:
+            line["psnr_vs_oracle_db"] = par["psnr_vs_oracle_db"]
+            line["loss_rel_vs_oracle"] = par["loss_rel_vs_oracle"]
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))

@@ -108,6 +108,8 @@ SIGNATURES = {
     "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_clamp_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_bicubic_blend": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]),
+    "nvq_mse_forward": (ci, [vp, vp, cl, vp, vp, sz, vp]),
+    "nvq_mse_backward": (ci, [vp, vp, cl, vp, vp, vp]),
     "nvq_axpy_slice": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, ci, cl, cf, ci, ci, vp]),
     "nvq_colsum": (ci, [vp, ci, ci, ci, cl, cf, vp, vp, sz, ci, vp]),
     "nvq_ewc_penalty": (ci, [vp, vp, vp, cl, cf, vp, vp, sz, vp]),
@@ -714,6 +716,15 @@ def colsum(x: Sl, out: torch.Tensor, ws, alpha=1.0, accumulate=False):
     npix = x.t.shape[0] * x.t.shape[1] * x.t.shape[2]
     check(lib().nvq_colsum(ptr(x.t), x.ld, x.coff, x.c, npix, alpha, ptr(out), ptr(ws), ws.numel() * 4,
                            int(accumulate), stream()), "nvq_colsum")
+
+
+# ----------------------------------------------------------------------------- loss
+def mse_forward(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, ws: torch.Tensor):
+    check(lib().nvq_mse_forward(ptr(a), ptr(b), a.numel(), ptr(out), ptr(ws), ws.numel() * 4, stream()), "nvq_mse_forward")
+
+
+def mse_backward(a: torch.Tensor, b: torch.Tensor, go_dev: Optional[torch.Tensor], da: torch.Tensor):
+    check(lib().nvq_mse_backward(ptr(a), ptr(b), a.numel(), ptr(go_dev), ptr(da), stream()), "nvq_mse_backward")
 
 
 # ----------------------------------------------------------------------------- EWC

@@ -13,7 +13,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader, TensorDataset
 
 from _common import compute_psnr, pick_device, shard
-from nerve_cl import parallel
+from nerve_cl import ops, parallel
 from nerve_cl.models import SuperResolutionNet
 
 
@@ -45,7 +45,7 @@ def train(args) -> None:
     say(f"  Parameters: {sum(p.numel() for p in model.parameters()):,}")
     optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=1e-5)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epochs)
-    criterion = nn.MSELoss()
+    criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
 
     say(f"\nTraining for {args.epochs} epochs...")
     say("-" * 60)

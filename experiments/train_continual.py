@@ -16,7 +16,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader, TensorDataset
 
 from _common import pick_device, shard
-from nerve_cl import parallel
+from nerve_cl import ops, parallel
 from nerve_cl.continual import EWC, EpisodicMemory, FOMAML, ContinualDistillation  # noqa: F401
 from nerve_cl.models import EnhancementConfig, EnhancementEngine
 
@@ -44,7 +44,7 @@ def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
     adapter = _ClipAdapter(model)
     ewc = EWC(adapter, ewc_lambda=config.get("ewc_lambda", 5000))
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
-    criterion = nn.MSELoss()
+    criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
     say = print if rank == 0 else (lambda *a, **k: None)
     for task_id, (task_name, (lr, hr)) in enumerate(tasks):
         say(f"\n=== Training on Task {task_id}: {task_name} ===")
@@ -70,7 +70,7 @@ def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
 def train_with_replay(model, tasks, memory, config, rank=0, epochs=5):
     device = next(model.parameters()).device
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
-    criterion = nn.MSELoss()
+    criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
     say = print if rank == 0 else (lambda *a, **k: None)
     for task_id, (task_name, (lr, hr)) in enumerate(tasks):
         say(f"\n=== Training on Task {task_id}: {task_name} ===")

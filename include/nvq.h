@@ -343,6 +343,15 @@ int nvq_bicubic_blend(const float* sr, const float* frames, int B, int T, int t_
 int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H,
                                int W, int s, float* du, int du_ld, void* stream);
 
+/* ------------------------------------------------------------------ loss
+ * nn.MSELoss() of the training loops (experiments/train_baseline.py:64,86, train_continual.py:31,55) and F.mse_loss of
+ * EWC.compute_fisher (ewc.py:125): *out = mean((a - b)^2) over n floats; workspace >= 8 KiB. */
+int nvq_mse_forward(const float* a, const float* b, long n, float* out, float* workspace,
+                    size_t workspace_bytes, void* stream);
+/* da = (*grad_out_dev) * 2 (a - b) / n  (grad_out_dev: device scalar, NULL for 1) */
+int nvq_mse_backward(const float* a, const float* b, long n, const float* grad_out_dev, float* da,
+                     void* stream);
+
 /* ------------------------------------------------------------------ small helpers */
 /* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C; src may be stored as
  * bf16 (src_bf16), dst and mask are fp32 */

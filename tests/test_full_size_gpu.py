@@ -40,15 +40,59 @@ def test_batch_independence_and_determinism(net, bf16):
     assert torch.equal(both[1:2], one)
     assert torch.equal(both, again)
     net.train()
-    grads = []
+    grads, bufs = [], []
+    start = {n: b.clone() for n, b in net.named_buffers()}
     for _ in range(2):
         net.zero_grad(set_to_none=True)
-        for b in net.buffers():                     # same BatchNorm running state for both runs
-            if b.dtype.is_floating_point:
-                b.copy_(torch.ones_like(b) if "var" in "running_var" and b.min() >= 0 and b.max() > 0 else b)
+        with torch.no_grad():
+            for n, b in net.named_buffers():        # same BatchNorm running state at the start of both runs
+                b.copy_(start[n])
         F.mse_loss(net(x[:1]), torch.full((1, 3, 2 * H, 2 * W), 0.5, device="cuda")).backward()
         grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
+        bufs.append(torch.cat([b.flatten().double() for b in net.buffers()]))
     assert torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1])
+    assert torch.equal(bufs[0], bufs[1])
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cfg4_sr_geometry_batch_independence_and_determinism(bf16):
+    """BASELINE cfg4's SR network (reference super_resolution.py:279-291 with scale_factor=4, temporal_window=2: T=5, the
+    320->64 attention conv, 64->5 logits, 64->48 upsampler) at its full size, 270x480 -> 1080x1920: the same
+    size-independent properties as above."""
+    from nerve_cl import _nvq
+    from nerve_cl.models import SuperResolutionNet
+    torch.manual_seed(4)
+    net4 = SuperResolutionNet(3, 4, 64, 8, 2).cuda()
+    net4.math_mode, net4.bf16_activations = (_nvq.MATH_BF16, True) if bf16 else (_nvq.MATH_F32, False)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.rand(2, 5, 3, 270, 480, device="cuda", generator=g)
+    net4.eval()
+    with torch.no_grad():
+        both = net4(x)
+        one = net4(x[1:2])
+        again = net4(x)
+    assert both.shape == (2, 3, 1080, 1920)
+    assert torch.equal(both[1:2], one) and torch.equal(both, again)
+    # the skip path alone: zeroed upsampler conv => clamp(bicubic x4 of the centre frame)
+    sd = {k: v.clone() for k, v in net4.state_dict().items()}
+    with torch.no_grad():
+        net4.upsampler.conv.weight.zero_()
+        net4.upsampler.conv.bias.zero_()
+        ref = F.interpolate(x[:, 2], scale_factor=4.0, mode="bicubic", align_corners=False).clamp(0, 1)
+        assert (net4(x) - ref).abs().max().item() < 2e-5
+    net4.load_state_dict(sd)
+    net4.train()
+    start = {n: b.clone() for n, b in net4.named_buffers()}
+    grads = []
+    for _ in range(2):
+        net4.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for n, b in net4.named_buffers():
+                b.copy_(start[n])
+        F.mse_loss(net4(x), torch.full((2, 3, 1080, 1920), 0.5, device="cuda")).backward()
+        grads.append(torch.cat([p.grad.flatten() for p in net4.parameters()]))
+    assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
     assert torch.equal(grads[0], grads[1])
 
 

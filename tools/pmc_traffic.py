@@ -1,7 +1,12 @@
 """Build profiles/<name>_traffic_pmc.json from two rocprofv3 counter-collection csv files (one --pmc FETCH_SIZE pass, one
---pmc WRITE_SIZE pass of the same bench.py command).  usage: pmc_traffic.py <fetch.csv> <write.csv> <out.json>
+--pmc WRITE_SIZE pass of the same bench.py command).
+usage: pmc_traffic.py <fetch.csv> <write.csv> <out.json> [<bench line json of the same command>]
+The bench line supplies the workload / batch, and the source fingerprint (bench.sources_sha) ties the summary to the
+sources it was measured at: bench.py quotes `roofline.traffic` only from a summary whose three keys match its own run.
 Per-launch HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md (HBM section)."""
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 LABELS = [(r"conv_bf16_kernel<2, 3", "conv_bf16_kernel<2,3>"), (r"conv_bf16_kernel<4, 3", "conv_bf16_kernel<4,3>"),
           (r"conv_bf16_kernel<4, 1", "conv_bf16_kernel<4,1>"), (r"wgrad_bf16_kernel<3", "wgrad_bf16_kernel<3>"),
@@ -32,5 +37,10 @@ for lab in fetch:
     w = sum(write[lab]) / max(len(write[lab]), 1)
     out["kernels"][lab] = {"launches": len(fetch[lab]), "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                            "hbm_bytes_per_launch": (2 * f + w) * 1024, "rocprof_names": sorted(names[lab])}
+import bench  # noqa: E402
+out["sources_sha"] = bench.sources_sha()
+if len(sys.argv) > 4:
+    line = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])
+    out["workload"], out["batch"] = line["config"]["workload"], line["config"]["per_gpu_batch"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in out["kernels"].items()}))
