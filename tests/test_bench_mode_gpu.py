@@ -61,14 +61,14 @@ def test_f64_fixture_in_the_benchmarked_mode(monkeypatch, planar, bf16feat):
     loss.backward()
     o_loss = F.mse_loss(ora(x), tgt)
     o_loss.backward()
-    ref_out = torch.from_numpy(g["out"])                      # the REFERENCE's output for these weights / inputs
+    ref_out = torch.from_numpy(g["output"])                      # the REFERENCE's output for these weights / inputs
     psnr = sr_oracle.compute_psnr(out.detach().cpu(), ref_out)
     cos_min, worst, flow_min = _grad_cosines(net, ora)
     print(f"  f64 fixture planar={planar} bf16feat={bf16feat}: PSNR vs reference {psnr:.1f} dB, loss {loss.item():.6f} vs "
           f"{float(g['loss']):.6f}, min grad cosine {cos_min:.5f} at {worst} (flow net {flow_min:.4f})")
-    assert psnr > 40.0
-    assert abs(loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
-    assert cos_min > 0.98
+    assert psnr > 43.0                                        # measured 46.6 dB
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"])     # measured 2.3e-4
+    assert cos_min > 0.975                                    # measured 0.983 (attention.0, a 1e-4-sized gradient)
 
 
 @pytest.mark.parametrize("planar,bf16feat", MODES[:2] + MODES[3:])
@@ -89,9 +89,9 @@ def test_bench_config_f64_n8_against_fp32_oracle(monkeypatch, planar, bf16feat):
     cos_min, worst, flow_min = _grad_cosines(net, ora)
     print(f"  F=64 N=8 planar={planar} bf16feat={bf16feat}: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs "
           f"{o_loss.item():.6f}, min grad cosine {cos_min:.5f} at {worst} (flow net {flow_min:.4f})")
-    assert psnr > 38.0
-    assert abs(loss.item() - o_loss.item()) < 5e-3 * o_loss.item()
-    assert cos_min > 0.97
+    assert psnr > 41.0                                        # measured 44.5 dB
+    assert abs(loss.item() - o_loss.item()) < 2e-3 * o_loss.item()     # measured 3.5e-4
+    assert cos_min > 0.985                                    # measured 0.995
     if (planar, bf16feat) != ("1", "1"):
         return
     # three AdamW steps from the same start: the bf16 trajectory tracks the fp32 one
