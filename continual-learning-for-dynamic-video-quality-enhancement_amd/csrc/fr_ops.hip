@@ -442,6 +442,17 @@ __global__ __launch_bounds__(256) void convt_unpack_kernel(const float* __restri
     dw[gid] = dw3[((((size_t)(py * 2 + px) * Co + co) * Ci + ci) * 3 + ty) * 3 + tx];
 }
 
+// nn.Conv3d(Ci, Co, (3,1,1)) weight [Co, Ci, 3] <-> three 1x1 conv weights [3][Co][Ci] (efficient_layers.py:271-278)
+__global__ __launch_bounds__(256) void tconv_relayout_kernel(const float* __restrict__ in, float* __restrict__ out, long CoCi,
+                                                             int to_taps) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= 3 * CoCi) return;
+    const long i = gid / 3;
+    const int k = (int)(gid % 3);                   // gid indexes the [Co*Ci][3] side
+    if (to_taps) out[(size_t)k * CoCi + i] = in[gid];
+    else out[gid] = in[(size_t)k * CoCi + i];
+}
+
 // ------------------------------------------------------------------------------------------------ small helpers
 // part[n][blk][c] = sum over the blk-th pixel range of image n (input of nvq_cbam_channel).  grid (nblk, N)
 __global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ x, int ld, int C, long HW,
@@ -831,6 +842,12 @@ int nvq_convt_unpack_grad(const float* dw3, int Ci, int Co, float* dw, void* str
     const long total = 16L * Co * Ci;
     hipLaunchKernelGGL(convt_unpack_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dw3, Ci, Co, dw, total);
     return check_launch("convt_unpack_grad");
+}
+
+int nvq_tconv_relayout(const float* in, float* out, int Co, int Ci, int to_taps, void* stream) {
+    const long n = (long)Co * Ci;
+    hipLaunchKernelGGL(tconv_relayout_kernel, dim3(blocks_for(3 * n)), dim3(256), 0, (hipStream_t)stream, in, out, n, to_taps);
+    return check_launch("tconv_relayout");
 }
 
 int nvq_gap_blocks(int H, int W) {

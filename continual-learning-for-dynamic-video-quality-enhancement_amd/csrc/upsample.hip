@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void shuffle_bicubic_clamp_kernel(const float*
     }
 }
 
+// plain nn.PixelShuffle(s) (efficient_layers.py:101-106) for the stand-alone PixelShuffleUpsampler module:
+// img[b, c, h*s+i, w*s+j] <-> u[b, h, w, c*s*s + i*s + j]; one thread per HR pixel, coalesced on the image side.
+// backward != 0: u is written from img (channels beyond C*s*s zero-filled by the thread of phase (0,0)).
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(float* __restrict__ u, int u_ld, int C, int H, int W, int s,
+                                                            float* __restrict__ img, long total, int backward) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int OW = W * s, OH = H * s;
+    const int ox = gid % OW;
+    const int oy = (gid / OW) % OH;
+    const int b = gid / ((long)OW * OH);
+    const int h = oy / s, i = oy - h * s, w = ox / s, j = ox - w * s;
+    float* up = u + ((size_t)(b * H + h) * W + w) * u_ld;
+    for (int c = 0; c < C; ++c) {
+        const size_t o = ((size_t)(b * C + c) * OH + oy) * OW + ox;
+        if (backward) up[c * s * s + i * s + j] = img[o];
+        else img[o] = up[c * s * s + i * s + j];
+    }
+    if (backward && i == 0 && j == 0)
+        for (int k = C * s * s; k < u_ld; ++k) up[k] = 0.f;
+}
+
 // one thread per LR pixel
 __global__ __launch_bounds__(256) void shuffle_clamp_bwd_kernel(const float* __restrict__ dout,
                                                                  const uint8_t* __restrict__ pass, int Cimg, int H,
@@ -135,6 +157,14 @@ int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, in
     hipLaunchKernelGGL(shuffle_clamp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
                        pass, Cimg, H, W, s, du, du_ld, total);
     return check_launch("shuffle_clamp_backward");
+}
+
+int nvq_pixel_shuffle(float* u, int u_ld, int B, int C, int H, int W, int s, float* img, int backward, void* stream) {
+    NVQ_REQUIRE(s >= 1 && s <= 8 && u_ld >= C * s * s, "pixel_shuffle: args");
+    const long total = (long)B * H * s * W * s;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, u, u_ld, C, H, W, s, img,
+                       total, backward);
+    return check_launch("pixel_shuffle");
 }
 
 }  // extern "C"

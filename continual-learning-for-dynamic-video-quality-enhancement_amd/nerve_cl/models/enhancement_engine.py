@@ -4,8 +4,8 @@ Mirrors the reference's interface (nerve_cl/models/enhancement_engine.py:18-292)
 ``EnhancementConfig`` fields and defaults, ``EnhancementEngine(config)`` attributes
 (``config``, ``frame_recovery``, ``super_resolution``, ``enhancement_strength``) and
 ``forward(frames, center_idx, corruption_mask, enhancement_strength) -> dict`` with keys
-'enhanced' (always), 'super_resolved', 'recovered'.  Only the super-resolution branch is
-on the MI355X hot path; the frame-recovery head is the first "next" row of SURVEY.md 8f.
+'enhanced' (always), 'super_resolved', 'recovered'.  Both branches run as libnvq HIP kernels: the
+super-resolution network is the hot path, the frame-recovery head its first "next" row (8f).
 """
 from __future__ import annotations
 
@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from nerve_cl import _nvq
+from nerve_cl.models.frame_recovery import FrameRecoveryNet
 from nerve_cl.models.super_resolution import LightweightSuperResolution, SuperResolutionNet
 
 
@@ -54,10 +55,12 @@ class EnhancementEngine(nn.Module):
     def __init__(self, config: Optional[EnhancementConfig] = None):
         super().__init__()
         self.config = config or EnhancementConfig()
-        # The inpainting head is not consumed by the SR output in the reference either
-        # (enhancement_engine.py:143-148 feeds the ORIGINAL frames to SR); it is not built yet.
-        self.frame_recovery = None
-        self._frame_recovery_requested = bool(self.config.frame_recovery_enabled)
+        # same construction order as the reference (:65-93), so default initialisation draws the same RNG stream
+        if self.config.frame_recovery_enabled:
+            self.frame_recovery = FrameRecoveryNet(base_channels=self.config.recovery_base_channels,
+                                                   temporal_window=self.config.recovery_temporal_window)
+        else:
+            self.frame_recovery = None
         if self.config.super_resolution_enabled:
             if self.config.use_lightweight_sr:
                 self.super_resolution = LightweightSuperResolution(scale_factor=self.config.scale_factor)
@@ -80,12 +83,15 @@ class EnhancementEngine(nn.Module):
             center_idx = T // 2
         results: Dict[str, torch.Tensor] = {}
         current = frames[:, center_idx]
-        if self._frame_recovery_requested and corruption_mask is not None:
-            # same guard as the reference (:130-131): recovery only runs on a non-empty mask
+        if self.frame_recovery is not None and corruption_mask is not None:
+            # same guard as the reference (:130-131): recovery only runs on a non-empty mask (one host sync, as there)
             if bool(corruption_mask.sum() > 0):
-                raise NotImplementedError(
-                    "FrameRecoveryNet is not built yet (SURVEY.md 8f row 1); pass corruption_mask=None "
-                    "or construct the engine with frame_recovery_enabled=False")
+                refs = frames[:, [i for i in range(T) if i != center_idx]]
+                results["recovered"] = self.frame_recovery(corrupted_frame=current, reference_frames=refs,
+                                                           corruption_mask=corruption_mask)
+                current = results["recovered"]
+                # (as in the reference, :139-163: the lightweight single-frame SR net is fed the recovered frame, the
+                # temporal SR net still reads the ORIGINAL frames; with SR disabled 'enhanced' is the recovered frame)
         if self.super_resolution is not None:
             w = self.config.sr_temporal_window
             lo, hi = max(0, center_idx - w), min(T, center_idx + w + 1)
@@ -155,6 +161,8 @@ class EnhancementEngine(nn.Module):
                 "trainable": sum(p.numel() for p in self.parameters() if p.requires_grad),
             },
         }
+        if self.frame_recovery is not None:
+            info["parameters"]["frame_recovery"] = sum(p.numel() for p in self.frame_recovery.parameters())
         if self.super_resolution is not None:
             info["parameters"]["super_resolution"] = sum(p.numel() for p in self.super_resolution.parameters())
         return info

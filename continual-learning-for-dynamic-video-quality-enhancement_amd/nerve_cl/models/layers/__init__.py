@@ -2,15 +2,17 @@
 from nerve_cl.models.layers.efficient_layers import (
     DepthwiseSeparableConv,
     PixelShuffleUpsampler,
+    ResidualBlock,
     ChannelAttention,
     SpatialAttention,
     CBAM,
+    TemporalConv3D,
     LiteFlowNetCorrelation,
     Stack,
     Act,
 )
 
 __all__ = [
-    "DepthwiseSeparableConv", "PixelShuffleUpsampler", "ChannelAttention", "SpatialAttention",
-    "CBAM", "LiteFlowNetCorrelation", "Stack", "Act",
+    "DepthwiseSeparableConv", "PixelShuffleUpsampler", "ResidualBlock", "ChannelAttention", "SpatialAttention",
+    "CBAM", "TemporalConv3D", "LiteFlowNetCorrelation", "Stack", "Act",
 ]

@@ -343,6 +343,11 @@ int nvq_bicubic_blend(const float* sr, const float* frames, int B, int T, int t_
 int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, int Cimg, int H,
                                int W, int s, float* du, int du_ld, void* stream);
 
+/* nn.PixelShuffle(s) alone (stand-alone PixelShuffleUpsampler, efficient_layers.py:101-106):
+ * img[b,c,h*s+i,w*s+j] = u[b,h,w,c*s*s+i*s+j] (backward != 0: the other direction, padding channels of u zeroed) */
+int nvq_pixel_shuffle(float* u, int u_ld, int B, int C, int H, int W, int s, float* img, int backward,
+                      void* stream);
+
 /* ------------------------------------------------------------------ loss
  * nn.MSELoss() of the training loops (experiments/train_baseline.py:64,86, train_continual.py:31,55) and F.mse_loss of
  * EWC.compute_fisher (ewc.py:125): *out = mean((a - b)^2) over n floats; workspace >= 8 KiB. */
@@ -351,6 +356,85 @@ int nvq_mse_forward(const float* a, const float* b, long n, float* out, float* w
 /* da = (*grad_out_dev) * 2 (a - b) / n  (grad_out_dev: device scalar, NULL for 1) */
 int nvq_mse_backward(const float* a, const float* b, long n, const float* grad_out_dev, float* da,
                      void* stream);
+
+/* ------------------------------------------------------------------ FrameRecoveryNet layers (csrc/fr_ops.hip)
+ * Generic fp32 NHWC kernels for reference nerve_cl/models/frame_recovery.py:23-446 (+ efficient_layers.py:109-151,
+ * 231-294).  Tensors are [N,H,W,ld] fp32, logical channel count C <= ld, ld % 4 == 0, channels [C, ld) kept 0. */
+/* dst[n,p,dst_coff+c] = src[n*src_nstride + c*H*W + p] (c < C), 0 for C <= c < czero: NCHW image (or frame t of a
+ * (B,T,C,H,W) clip: src + t*C*H*W, src_nstride = T*C*H*W) into an NHWC slice */
+int nvq_nchw_to_nhwc(const float* src, long src_nstride, int N, int C, int H, int W, float* dst,
+                     int dst_ld, int dst_coff, int czero, void* stream);
+int nvq_nhwc_to_nchw(const float* src, int src_ld, int src_coff, int N, int C, int H, int W,
+                     float* dst, long dst_nstride, void* stream);
+/* nn.BatchNorm2d / BatchNorm3d (frame_recovery.py:45,73,285-305; efficient_layers.py:139,266,279) for any C: statistics
+ * over all npix pixels (train: batch mean / biased variance, running statistics updated with the unbiased variance;
+ * running_mean may be NULL), then y = bn(x) (+ res) (ReLU if relu).  workspace >= nvq_bn2_workspace_bytes(C)
+ * (+ 2*C floats for the backward). */
+size_t nvq_bn2_workspace_bytes(int C);
+int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float momentum, float* mean,
+                  float* invstd, float* running_mean, float* running_var, float* workspace,
+                  size_t workspace_bytes, void* stream);
+int nvq_bn2_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                       float* mean, float* invstd, void* stream);
+int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, const float* res, int res_ld, int relu,
+                  float* out, int out_ld, void* stream);
+/* g = dy masked by the forward ReLU (recomputed from x, res); dgamma = sum g*xhat, dbeta = sum g; dx as BatchNorm's
+ * backward (training) or gamma*invstd*g (eval); dres = g when res != NULL */
+int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C, long npix,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const float* res, int res_ld, int relu, int training, float* dx, int dx_ld,
+                     float* dres, int dres_ld, float* dgamma, float* dbeta, float* workspace,
+                     size_t workspace_bytes, void* stream);
+/* nn.MaxPool2d(k, s, pad) (frame_recovery.py:46) and F.max_pool3d(x, (1,2,2)) (:155,158): first maximum in scan order
+ * wins (PyTorch's tie rule, matters after ReLU); idx = one byte per element; the backward is a gather (no atomics) */
+int nvq_maxpool_forward(const float* x, int ld, int N, int H, int W, int k, int s, int pad, float* out,
+                        uint8_t* idx, void* stream);
+int nvq_maxpool_backward(const float* dy, const uint8_t* idx, int ld, int N, int H, int W, int k, int s,
+                         int pad, float* dx, void* stream);
+/* input side of nn.Conv2d(k=1, stride=2) (frame_recovery.py:71): out[n,y,x] = in[n,2y,2x]; backward = zero insertion
+ * (in = gradient at the subsampled size, out = gradient at H x W) */
+int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int backward, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) (frame_recovery.py:224-229,433-436); backward (gather form):
+ * in = dy [N,OH,OW], out = dx [N,H,W] */
+int nvq_bilinear_resize(const float* in, int ld, int N, int H, int W, int OH, int OW, float* out,
+                        int backward, void* stream);
+/* nn.ConvTranspose2d(k=4, s=2, p=1) (frame_recovery.py:283-304) = 3x3 conv to 4*Co phase-major channels followed by
+ * depth-to-space: nvq_convt_pack builds the [4*Co, Ci, 3, 3] conv weight from [Ci, Co, 4, 4], nvq_convt_unpack_grad
+ * maps its gradient back, nvq_depth_space2 moves [N,H,W,4*Co] <-> [N,2H,2W,Co] */
+int nvq_convt_pack(const float* w, int Ci, int Co, float* w3, void* stream);
+int nvq_convt_unpack_grad(const float* dw3, int Ci, int Co, float* dw, void* stream);
+int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, void* stream);
+/* TemporalConv3D's nn.Conv3d(Ci, Co, (3,1,1)) weight [Co,Ci,3,1,1] (efficient_layers.py:271-278) -> three 1x1 conv
+ * weights [3][Co][Ci] (to_taps = 1) and back (its gradient, to_taps = 0): the temporal conv runs as three accumulating
+ * 1x1 convolutions over time-shifted image ranges */
+int nvq_tconv_relayout(const float* in, float* out, int Co, int Ci, int to_taps, void* stream);
+/* per-image partial channel sums [N][nvq_gap_blocks(H,W)][C]: the input of nvq_cbam_channel for a stand-alone CBAM */
+int nvq_gap_blocks(int H, int W);
+int nvq_gap_partial(const float* x, int ld, int C, int N, int H, int W, float* part, void* stream);
+/* x[n,p,c] += v[n,c] (gradient of the global average pool) */
+int nvq_add_image_channel(float* x, int ld, int C, int N, int H, int W, const float* v, void* stream);
+/* nn.Tanh (frame_recovery.py:309): out = tanh(a) | backward: out = a * (1 - y^2) */
+int nvq_tanh(const float* a, const float* y, long n, float* out, int backward, void* stream);
+/* FusionModule (frame_recovery.py:239-254): out = aligned + a0*mean_c(sp) + a1*mean_c(tp), (a0,a1) = softmax(logits[0:2]);
+ * attn / means: [npix][2] saved for the backward; C a power of two in [16,256]; aligned / out / dy have ld = C */
+int nvq_fusion_mix_forward(const float* aligned, const float* logits, int logits_ld, const float* sp,
+                           int sp_ld, const float* tp, int tp_ld, int C, long npix, float* out,
+                           float* attn, float* means, void* stream);
+int nvq_fusion_mix_backward(const float* dy, const float* attn, const float* means, int C, long npix,
+                            float* dlogits, int logits_ld, float* dsp, int sp_ld, float* dtp, int tp_ld,
+                            void* stream);
+/* FrameRecoveryNet blend (frame_recovery.py:439-440): out = frame*(1-m) + rec*m; frame/out NCHW, rec NHWC, m [N,1,H,W] */
+int nvq_mask_blend(const float* frame, const float* rec, int rec_ld, const float* mask, int N, int C,
+                   int H, int W, float* out, void* stream);
+int nvq_mask_blend_backward(const float* dout, const float* mask, int N, int C, int H, int W,
+                            float* drec, int rec_ld, void* stream);
+/* SpatialEncoder stem nn.Conv2d(4, Co, 7, 2, 3, bias=False) (frame_recovery.py:42-44) on a 4-channel NHWC image;
+ * w / dw in PyTorch layout [Co,4,7,7]; wgrad workspace >= 256*64*196 floats */
+int nvq_stem7_forward(const float* x, const float* w, int N, int H, int W, int Co, float* out, int out_ld,
+                      void* stream);
+int nvq_stem7_wgrad(const float* x, const float* dy, int dy_ld, int N, int H, int W, int Co, float* dw,
+                    float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ small helpers */
 /* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C; src may be stored as

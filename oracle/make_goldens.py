@@ -231,6 +231,30 @@ def run_default_init(RefSR):
     print("default init:", len(blob), "tensors")
 
 
+def run_default_init_fr():
+    """Default initialisation of the reference's FrameRecoveryNet (base 16 and the default 64) and of a default
+    EnhancementEngine() under torch.manual_seed(0): the construction-order pin of the drop-in's inpainting head."""
+    from nerve_cl.models import EnhancementEngine as RefEngine
+    from nerve_cl.models.frame_recovery import FrameRecoveryNet as RefFR
+    blob = {}
+
+    def add(tag, module):
+        for n, t in module.state_dict().items():
+            f = t.detach().double().reshape(-1)
+            head = np.zeros(4)
+            head[:min(4, f.numel())] = f[:4].numpy()
+            blob[f"{tag}/{n}"] = np.concatenate([[f.sum().item(), f.norm().item()], head])
+
+    torch.manual_seed(0)
+    add("fr16", RefFR(3, 16, 2))
+    torch.manual_seed(0)
+    add("fr64", RefFR())
+    torch.manual_seed(0)
+    add("engine", RefEngine())
+    np.savez_compressed(os.path.join(OUT, "fr_default_init_seed0.npz"), **blob)
+    print("FR / engine default init:", len(blob), "tensors")
+
+
 LIGHT_CASES = {"light_s2_train": (2, 2, 12, 20, True), "light_s3_eval": (3, 1, 9, 14, False)}
 
 
@@ -324,6 +348,9 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     RefSR, RefEWC = import_reference()
+    if "--only-fr-init" in sys.argv:
+        run_default_init_fr()
+        return
     if "--only-fr" in sys.argv:
         for name, cfg in FR_CASES.items():
             run_fr(name, cfg)
@@ -339,6 +366,7 @@ def main():
     run_default_init(RefSR)
     for name, cfg in FR_CASES.items():
         run_fr(name, cfg)
+    run_default_init_fr()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {OUT}: {total/1024:.0f} KiB")
 

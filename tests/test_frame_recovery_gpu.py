@@ -1,0 +1,199 @@
+"""GPU: nerve_cl.models.FrameRecoveryNet (reference nerve_cl/models/frame_recovery.py:335-446) through
+libnvq against (1) the fixtures captured from the reference (tests/golden/fr_b16_{train,eval}.npz: output, loss, the
+summaries of all 117 parameter gradients, BatchNorm buffers) and (2) the CPU oracle (oracle/fr_oracle.py) on the same
+inputs - every gradient in full.  fp32 math: 1e-3 relative as north_star asks (measured ~1e-5); bf16 MFMA operands are
+judged by PSNR / gradient direction.  Also the engine surface that uses the network (enhancement_engine.py:62-82,130-138)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fr_oracle, synth
+from oracle.make_goldens import grad_summary
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLD, "fr_*.npz")))
+REL = 1e-3
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a)).double() if not torch.is_tensor(a) else a.detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def inputs(B, T, H, W):
+    clip = synth.formula_clip(B, T + 1, H, W)
+    corrupted, refs = clip[:, 0].contiguous(), clip[:, 1:].contiguous()
+    mask = torch.zeros(B, 1, H, W)
+    mask[:, :, H // 4:H // 4 + H // 2, W // 3:W // 3 + W // 2] = 1.0
+    return corrupted * (1 - mask), refs, mask, synth.formula_target(B, H, W)
+
+
+def build(base, T, train):
+    from nerve_cl.models import FrameRecoveryNet
+    sd = synth.formula_state_fr(3, base, gain=synth.GOLDEN_GAIN)
+    net = FrameRecoveryNet(3, base, T)
+    net.load_state_dict(sd, strict=True)                      # the reference's state_dict keys, all of them
+    net = net.cuda().train(train)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    return net, P
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_against_reference_fixture_and_oracle(path):
+    g = np.load(path)
+    base, B, T, H, W, train = [int(v) for v in g["cfg"]]
+    net, P = build(base, T, bool(train))
+    corrupted, refs, mask, tgt = inputs(B, T, H, W)
+    out = net(corrupted.cuda(), refs.cuda(), mask.cuda())
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    o_out = fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, bool(train))
+    F.mse_loss(o_out, tgt).backward()
+    # forward: reference fixture, oracle
+    assert out.shape == (B, 3, H, W)
+    assert rel(out, g["output"]) < REL and rel(out, o_out) < REL
+    assert abs(loss.item() - float(g["loss"])) < REL * float(g["loss"])
+    assert torch.equal(out.cpu() * (1 - mask), corrupted * (1 - mask))     # uncorrupted pixels pass through (:439)
+    # gradients: all 117 tensors in full vs the oracle, summaries vs the reference fixture
+    worst, seen = 0.0, 0
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        e = rel(p.grad, P[n].grad)
+        worst = max(worst, e)
+        assert e < REL, (n, e)
+        ref, got = g["gsum/" + n], grad_summary(p.grad.cpu())
+        assert abs(got[1] - ref[1]) <= REL * max(ref[1], 1e-12), n
+        assert np.abs(got[2:] - ref[2:]).max() <= REL * max(np.abs(ref[2:]).max(), ref[1] * 1e-2), n
+        seen += 1
+    assert seen == 117
+    sd = net.state_dict()
+    nbuf = 0
+    for key in g.files:
+        if key.startswith("buf/"):
+            assert rel(sd[key[4:]].double(), g[key]) < REL, key
+            nbuf += 1
+    for n, v in P.items():                                    # every BatchNorm buffer vs the oracle after the call
+        if "running" in n or "num_batches" in n:
+            assert rel(sd[n].double(), v.double()) < REL, n
+    assert nbuf > 0
+    print(f"{os.path.basename(path)}: out err {rel(out, g['output']):.2e}, worst grad rel err vs oracle {worst:.2e}")
+
+
+def test_no_mask_eval_nograd_and_default_mask():
+    net, P = build(16, 2, False)
+    corrupted, refs, mask, _ = inputs(1, 2, 48, 64)
+    with torch.no_grad():
+        a = net(corrupted.cuda(), refs.cuda(), mask.cuda())
+        b = net(corrupted.cuda(), refs.cuda())                # mask None = zeros: output is the input frame (:418-419,439)
+    assert rel(a, fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, False)) < REL
+    assert torch.equal(b.cpu(), corrupted)
+    assert net.get_num_parameters() == sum(p.numel() for p in net.parameters())
+    with pytest.raises(RuntimeError):
+        net(corrupted, refs, mask)                            # CPU tensors: no fallback
+
+
+def test_bf16_math_mode_quality():
+    from nerve_cl import _nvq
+    net, P = build(16, 2, True)
+    net.math_mode = _nvq.MATH_BF16
+    corrupted, refs, mask, tgt = inputs(2, 2, 64, 64)
+    out = net(corrupted.cuda(), refs.cuda(), mask.cuda())
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    o_out = fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, True)
+    o_loss = F.mse_loss(o_out, tgt)
+    o_loss.backward()
+    mse = F.mse_loss(out.cpu(), o_out).item()
+    psnr = 10 * np.log10(4.0 / max(mse, 1e-30))               # tanh output: range [-1, 1]
+    cos_min, worst = 1.0, None
+    for n, p in net.named_parameters():
+        a, b = p.grad.double().cpu().reshape(-1), P[n].grad.double().reshape(-1)
+        if b.norm() < 1e-12:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        if cos < cos_min:
+            cos_min, worst = cos, n
+    print(f"  FR bf16 math: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, "
+          f"min grad cosine {cos_min:.4f} at {worst}")
+    assert psnr > 35.0 and abs(loss.item() - o_loss.item()) < 1e-2 * o_loss.item() and cos_min > 0.95
+
+
+def test_engine_default_constructs_frame_recovery_with_reference_keys_and_recovers():
+    """EnhancementEngine() (reference enhancement_engine.py:62-93): frame_recovery.* keys present, 'recovered' returned
+    for a non-empty mask (:130-138), both heads receive gradients with the two-term loss of SURVEY.md 8(d) cfg4."""
+    from nerve_cl.models import EnhancementConfig, EnhancementEngine, FrameRecoveryNet
+    torch.manual_seed(0)
+    eng = EnhancementEngine(EnhancementConfig(recovery_base_channels=16, sr_num_features=16, sr_num_residual_blocks=1))
+    assert isinstance(eng.frame_recovery, FrameRecoveryNet)
+    shapes, buffers = fr_oracle.shapes(3, 16)
+    keys = {k for k in eng.state_dict() if k.startswith("frame_recovery.")}
+    assert keys == {"frame_recovery." + n for n in list(shapes) + list(buffers)}
+    sd = eng.state_dict()
+    assert all(tuple(sd["frame_recovery." + n].shape) == tuple(s) for n, s in shapes.items())
+    eng = eng.cuda().train()
+    frames = torch.rand(2, 5, 3, 32, 48, device="cuda")
+    mask = torch.zeros(2, 1, 32, 48, device="cuda")
+    res = eng(frames, corruption_mask=mask)                   # empty mask: recovery skipped (:131)
+    assert set(res) == {"super_resolved", "enhanced"}
+    mask[:, :, 8:24, 12:36] = 1.0
+    res = eng(frames, corruption_mask=mask)
+    assert set(res) == {"recovered", "super_resolved", "enhanced"}
+    assert res["recovered"].shape == (2, 3, 32, 48) and res["enhanced"].shape == (2, 3, 64, 96)
+    hr = torch.rand(2, 3, 64, 96, device="cuda")
+    (F.mse_loss(res["enhanced"], hr) + F.mse_loss(res["recovered"], frames[:, 2])).backward()
+    for n, p in eng.named_parameters():
+        assert (p.grad is not None) == (n != "enhancement_strength"), n
+    assert eng.frame_recovery._last_grad_bucket is not None and eng.super_resolution._last_grad_bucket is not None
+    info = eng.get_model_info()
+    assert info["parameters"]["frame_recovery"] == eng.frame_recovery.get_num_parameters()
+
+
+def test_frame_recovery_bucket_feeds_ewc_and_the_fused_penalty():
+    """the flat gradient bucket makes FrameRecoveryNet a first-class citizen of EWC: Fisher from the bucket, penalty gradient
+    added into the bucket by one kernel"""
+    from nerve_cl.continual import EWC
+    net, _ = build(16, 2, True)
+    corrupted, refs, mask, tgt = inputs(2, 2, 32, 48)
+    c, r, m, t = corrupted.cuda(), refs.cuda(), mask.cuda(), tgt.cuda()
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, fr):
+            super().__init__()
+            self.fr = fr
+
+        def forward(self, x):
+            return self.fr(x, r, m)
+
+    model = Wrap(net)
+    ewc = EWC(model, ewc_lambda=100.0)
+    ewc.register_task(0, [(c, t)])
+    fisher = torch.cat([ewc.fisher_dict[n].reshape(-1) for n, _ in model.named_parameters()])
+    net.eval()
+    model.zero_grad()
+    F.mse_loss(model(c), t).backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert rel(fisher, gref * gref / 2) < 1e-5                # one batch of 2 samples: g^2 / N
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01)
+    net.train()
+    model.zero_grad()
+    out = model(c)
+    loss = F.mse_loss(out, t) + ewc.penalty()
+    loss.backward()
+    assert net._deferred_adds == []
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    net2, _ = build(16, 2, True)
+    with torch.no_grad():
+        for p in net2.parameters():
+            p.add_(0.01)
+    F.mse_loss(net2(c, r, m), t).backward()
+    data = torch.cat([p.grad.reshape(-1) for p in net2.parameters()])
+    want = data + 100.0 * fisher * 0.01
+    assert rel(got, want) < 1e-4

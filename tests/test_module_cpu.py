@@ -94,3 +94,32 @@ def test_engine_surface():
             cfg.super_resolution_enabled, cfg.scale_factor, cfg.sr_num_features, cfg.sr_num_residual_blocks,
             cfg.sr_temporal_window, cfg.use_lightweight_sr, cfg.enhancement_mode, cfg.upscale_first) == \
         (True, 64, 2, True, 2, 64, 8, 1, False, "sequential", False)
+
+
+def _checksums(sd):
+    out = {}
+    for n, t in sd.items():
+        f = t.double().reshape(-1)
+        head = np.zeros(4)
+        head[:min(4, f.numel())] = f[:4].numpy()
+        out[n] = np.concatenate([[f.sum().item(), f.norm().item()], head])
+    return out
+
+
+@pytest.mark.parametrize("tag", ["fr16", "fr64", "engine"])
+def test_frame_recovery_and_default_engine_state_dict_and_default_init_equal_the_reference(tag):
+    """FrameRecoveryNet (reference frame_recovery.py:361-395) and EnhancementEngine() (enhancement_engine.py:62-93): the
+    reference's state_dict keys / shapes, and - same construction order, same RNG stream - its default weights."""
+    from nerve_cl.models import EnhancementEngine, FrameRecoveryNet
+    g = np.load(os.path.join(GOLD, "fr_default_init_seed0.npz"))
+    torch.manual_seed(0)
+    m = FrameRecoveryNet(3, 16, 2) if tag == "fr16" else FrameRecoveryNet() if tag == "fr64" else EnhancementEngine()
+    got = _checksums(m.state_dict())
+    keys = [k[len(tag) + 1:] for k in g.files if k.startswith(tag + "/")]
+    assert sorted(keys) == sorted(got)
+    for n in keys:
+        assert np.allclose(got[n], g[f"{tag}/{n}"], rtol=1e-12, atol=1e-12), n
+    if tag == "fr64":
+        assert len(list(m.parameters())) == 117
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 2, 3, 64, 64))      # CPU tensors: no fallback

@@ -23,6 +23,19 @@ def _free_port() -> int:
     return port
 
 
+def _get(q, procs, timeout: float = 240.0):
+    """q.get() that fails instead of hanging when a worker died (the payload must be read BEFORE the producer exits: its
+    tensors travel as shared-memory handles)"""
+    import time
+    t0 = time.time()
+    while q.empty():
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        assert not dead, f"worker exited with {dead}"
+        assert time.time() - t0 < timeout, "workers timed out"
+        time.sleep(0.05)
+    return q.get()
+
+
 def _flat_grads(model, x, y):
     model.zero_grad()
     F.mse_loss(model(x), y).backward()
@@ -60,7 +73,7 @@ def _worker(rank: int, world: int, port: int, q):
     parallel.allreduce_sum_(fisher)
     fisher /= 4
     if rank == 0:
-        q.put((flat, fisher))
+        q.put((flat.numpy(), fisher.numpy()))          # by value: shared-memory handles die with the producer
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,7 +86,7 @@ def test_world2_bucket_allreduce_broadcast_and_fisher():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    flat, fisher = q.get()
+    flat, fisher = [torch.from_numpy(a) for a in _get(q, procs)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -124,8 +137,9 @@ def test_enable_data_parallel_installs_bucket_hook():
 # penalty gradient applied AFTER the bucket all-reduce - so the three kernels are replaced by their torch formulas (in this
 # test only) and the network is a two-tensor linear model with a hand-written bucket backward.
 def _install_cpu_kernels():
-    from nerve_cl import _engine, _nvq
+    from nerve_cl import _engine, _nvq, ops
     from nerve_cl.continual import ewc as ewc_mod
+    ops.mse_loss = F.mse_loss
     _nvq.fisher_accumulate = lambda g, f: f.add_(g * g)
     _nvq.ewc_penalty = lambda th, st, fi, lam, out, ws: out.copy_((0.5 * lam * (fi * (th - st) ** 2).sum()).reshape(1))
 
@@ -246,7 +260,7 @@ def _ewc_worker(rank: int, world: int, port: int, q):
     gl = data_l / world + pen_l
     grads = [model.net.lin.weight.grad.clone(), model.net.lin.bias.grad.clone(), gl]
     if rank == 0:
-        q.put((fisher, grads))
+        q.put(([f.numpy() for f in fisher], [g.numpy() for g in grads]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -259,7 +273,7 @@ def test_world2_ewc_fisher_and_deferred_penalty_through_the_bucket_hook():
     procs = [ctx.Process(target=_ewc_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    fisher, grads = q.get()
+    fisher, grads = [[torch.from_numpy(a) for a in part] for part in _get(q, procs)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
