@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-extras", action="store_true",
                     help="skip the cfg1 CPU timing and the full-size CPU inference forward of the cpu_baseline leg")
+    ap.add_argument("--recovery", action="store_true",
+                    help="BASELINE cfg4: EnhancementEngine = this SR net + the FrameRecoveryNet inpainting head (base 64), a "
+                         "rectangular mask over 25 %% of the frame, loss = MSE(enhanced, hr) + MSE(recovered, lr_centre) "
+                         "(SURVEY.md 8d)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape table of the conv launches to stderr")
     args = ap.parse_args()
@@ -228,25 +232,47 @@ def main():
 
     is_cfg2 = (cfg["scale"], cfg["F"], cfg["blocks"], cfg["T"], cfg["H"], cfg["W"]) == (2, 64, 8, 3, 540, 960)
     is_cfg4 = (cfg["scale"], cfg["F"], cfg["blocks"], cfg["T"], cfg["H"], cfg["W"]) == (4, 64, 8, 5, 270, 480)
-    tag = "cfg2" if is_cfg2 else "cfg4 (SR part)" if is_cfg4 else "custom"
+    tag = "cfg2" if is_cfg2 else ("cfg4" if args.recovery else "cfg4 (SR part)") if is_cfg4 else "custom"
     workload = (f"{tag}: SuperResolutionNet(scale={cfg['scale']}, feat={cfg['F']}, blocks={cfg['blocks']}, T={cfg['T']}) "
-                f"train step on {cfg['H']}x{cfg['W']} -> {cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips")
+                + ("+ FrameRecoveryNet(base=64) inpainting head (25 % mask, two-term loss) " if args.recovery else "")
+                + f"train step on {cfg['H']}x{cfg['W']} -> {cfg['H'] * cfg['scale']}x{cfg['W'] * cfg['scale']} clips")
 
     torch.manual_seed(0)
-    net = SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).to(dev).train()
+    engine = None
+    if args.recovery:
+        from nerve_cl.models import EnhancementConfig, EnhancementEngine
+        engine = EnhancementEngine(EnhancementConfig(
+            scale_factor=cfg["scale"], sr_num_features=cfg["F"], sr_num_residual_blocks=cfg["blocks"],
+            sr_temporal_window=cfg["window"], recovery_base_channels=64, recovery_temporal_window=cfg["window"])).to(dev).train()
+        net = engine.super_resolution
+        engine.frame_recovery.math_mode = _nvq.MATH_BF16 if args.math == "bf16" else _nvq.MATH_F32
+    else:
+        net = SuperResolutionNet(3, cfg["scale"], cfg["F"], cfg["blocks"], cfg["window"]).to(dev).train()
+    model = engine if engine is not None else net
     net.math_mode = _nvq.MATH_BF16 if args.math == "bf16" else _nvq.MATH_F32
     net.bf16_activations = args.math == "bf16" and not args.fp32_acts
     if world > 1:
-        parallel.enable_data_parallel(net)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-5)
+        parallel.enable_data_parallel(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
     x = torch.rand(B, cfg["T"], 3, cfg["H"], cfg["W"], device=dev, generator=g)
     y = torch.rand(B, 3, cfg["H"] * cfg["scale"], cfg["W"] * cfg["scale"], device=dev, generator=g)
+    mask = None
+    if args.recovery:                            # ones over the central quarter of the frame
+        mask = torch.zeros(B, 1, cfg["H"], cfg["W"], device=dev)
+        mask[:, :, cfg["H"] // 4:cfg["H"] // 4 + cfg["H"] // 2, cfg["W"] // 4:cfg["W"] // 4 + cfg["W"] // 2] = 1.0
+        x_centre = x[:, cfg["T"] // 2].contiguous()
 
     def step():
         opt.zero_grad()
-        loss = ops.mse_loss(net(x), y)          # nn.MSELoss of the reference loop as libnvq kernels
+        if engine is None:
+            loss = ops.mse_loss(net(x), y)      # nn.MSELoss of the reference loop as libnvq kernels
+        else:
+            # the second term is what gives the recovery head a gradient: its output does not feed the SR result
+            # (reference enhancement_engine.py:143-148)
+            res = engine(x, corruption_mask=mask)
+            loss = ops.mse_loss(res["enhanced"], y) + ops.mse_loss(res["recovered"], x_centre)
         loss.backward()
         opt.step()
         return loss

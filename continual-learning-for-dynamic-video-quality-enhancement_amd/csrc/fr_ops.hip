@@ -682,12 +682,15 @@ __global__ __launch_bounds__(256) void stem7_wgrad_kernel(const float* __restric
             }
         }
     }
-    // part[blk][co][ci][ky][kx]  (PyTorch weight order inside a slab of 64 * 196)
+    // part[blk][co][ci][ky][kx]  (PyTorch weight order inside a slab of cn * 196, cn = channels of this pass)
+    const int cn = Co - co0 < 64 ? Co - co0 : 64;
+    if (lane < cn) {
 #pragma unroll
-    for (int j = 0; j < 49; ++j) {
-        const int k = wave + 4 * j;
-        const int ci = k & 3, t = k >> 2;
-        part[((size_t)blockIdx.x * 64 + lane) * 196 + ci * 49 + t] = acc[j];
+        for (int j = 0; j < 49; ++j) {
+            const int k = wave + 4 * j;
+            const int ci = k & 3, t = k >> 2;
+            part[((size_t)blockIdx.x * cn + lane) * 196 + ci * 49 + t] = acc[j];
+        }
     }
 }
 

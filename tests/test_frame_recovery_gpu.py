@@ -16,7 +16,7 @@ from oracle.make_goldens import grad_summary
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(glob.glob(os.path.join(GOLD, "fr_*.npz")))
+CASES = sorted(glob.glob(os.path.join(GOLD, "fr_b*.npz")))
 REL = 1e-3
 
 
@@ -111,17 +111,24 @@ def test_bf16_math_mode_quality():
     o_loss.backward()
     mse = F.mse_loss(out.cpu(), o_out).item()
     psnr = 10 * np.log10(4.0 / max(mse, 1e-30))               # tanh output: range [-1, 1]
+    # direction of the whole gradient, and of every tensor that carries a visible share of it (the attention MLPs'
+    # gradients are ~1e-4 of the largest tensor's: bf16 rounding noise decides their direction)
+    ga = torch.cat([p.grad.double().cpu().reshape(-1) for _, p in net.named_parameters()])
+    gb = torch.cat([P[n].grad.double().reshape(-1) for n, _ in net.named_parameters()])
+    cos_all = float((ga @ gb) / (ga.norm() * gb.norm()))
+    big = max(P[n].grad.norm().item() for n, _ in net.named_parameters())
     cos_min, worst = 1.0, None
     for n, p in net.named_parameters():
         a, b = p.grad.double().cpu().reshape(-1), P[n].grad.double().reshape(-1)
-        if b.norm() < 1e-12:
+        if b.norm() < 1e-2 * big:
             continue
         cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
         if cos < cos_min:
             cos_min, worst = cos, n
-    print(f"  FR bf16 math: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, "
-          f"min grad cosine {cos_min:.4f} at {worst}")
-    assert psnr > 35.0 and abs(loss.item() - o_loss.item()) < 1e-2 * o_loss.item() and cos_min > 0.95
+    print(f"  FR bf16 math: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, gradient "
+          f"cosine {cos_all:.5f}, min over the large tensors {cos_min:.4f} at {worst}")
+    assert psnr > 40.0 and abs(loss.item() - o_loss.item()) < 5e-3 * o_loss.item()
+    assert cos_all > 0.995 and cos_min > 0.97
 
 
 def test_engine_default_constructs_frame_recovery_with_reference_keys_and_recovers():

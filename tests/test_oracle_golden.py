@@ -139,7 +139,7 @@ def test_light_matches_reference_fixture(path):
             assert _rel(P[key[4:]].double().numpy(), g[key]) < 1e-5, key
 
 
-FR = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fr_*.npz")))
+FR = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fr_b*.npz")))
 
 
 @pytest.mark.parametrize("path", FR, ids=[os.path.basename(p)[:-4] for p in FR])
