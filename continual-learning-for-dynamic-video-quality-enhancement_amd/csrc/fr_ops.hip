@@ -53,12 +53,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm, any C
-constexpr int BN2_MAXBLK = 512;
+constexpr int BN2_MAXBLK = 1024;
 
-// per-channel partial sums over a contiguous pixel range per workgroup: part[blk][0][c] = sum a, part[blk][1][c] = sum a*b'
-// MODE 0 (forward statistics): a = x, second sum = x^2.
+// A thread owns one 4-channel group g of a pixel row; the 256 / G4 threads that share g are summed through LDS.
+// part[blk][0][c] = sum a, part[blk][1][c] = sum b over the workgroup's pixel range:
+// MODE 0 (forward statistics): a = x, b = x^2.
 // MODE 1 (backward): g = dy masked by the ReLU of the forward output (relu != 0: y = bn(x) (+ res) > 0), a = g,
-//                    second sum = g * xhat; g is also written to gout when gout != nullptr.
+//                    b = g * xhat; g is also written to gout when gout != nullptr.
+// Padding channels (>= C) of every tensor are zero, so whole float4 groups are processed without channel masks; the
+// per-channel parameter arrays are read through cpar(), which guards the last partial group.
+__device__ __forceinline__ float4 cpar(const float* __restrict__ p, int c, int C) {
+    return make_float4(p[c], c + 1 < C ? p[c + 1] : 0.f, c + 2 < C ? p[c + 2] : 0.f, c + 3 < C ? p[c + 3] : 0.f);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                           const float* __restrict__ dy, int dy_ld,
@@ -67,43 +74,73 @@ __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int relu, float* __restrict__ gout, int gout_ld,
                                                           float* __restrict__ part) {
-    __shared__ float red[2][4][64];
-    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    __shared__ float red[256 * 8];
+    const int G4 = (C + 3) >> 2;
+    const int rows = 256 / G4;                       // pixel rows handled per iteration (G4 <= 256)
+    const int g = threadIdx.x % G4, row = threadIdx.x / G4;
+    const int c = 4 * g;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + lane;
-        float s0 = 0.f, s1 = 0.f;
-        if (c < C) {
-            float m = 0.f, is = 0.f, ga = 0.f, be = 0.f;
-            if (MODE == 1) { m = mean[c]; is = invstd[c]; ga = gamma[c]; be = beta[c]; }
-            for (long p = p0 + row; p < p1; p += 4) {
-                const float v = x[p * x_ld + c];
-                if (MODE == 0) {
-                    s0 += v;
-                    s1 += v * v;
-                } else {
-                    const float xh = (v - m) * is;
-                    float g = dy[p * dy_ld + c];
-                    if (relu) {
-                        float y = xh * ga + be;
-                        if (res) y += res[p * res_ld + c];
-                        if (!(y > 0.f)) g = 0.f;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), is = m, ga = m, be = m;
+        if (MODE == 1) { m = cpar(mean, c, C); is = cpar(invstd, c, C); ga = cpar(gamma, c, C); be = cpar(beta, c, C); }
+        for (long p = p0 + row; p < p1; p += rows) {
+            const float4 v = ld4(x + p * x_ld + c);
+            if (MODE == 0) {
+                s0[0] += v.x; s0[1] += v.y; s0[2] += v.z; s0[3] += v.w;
+                s1[0] += v.x * v.x; s1[1] += v.y * v.y; s1[2] += v.z * v.z; s1[3] += v.w * v.w;
+            } else {
+                const float xh[4] = {(v.x - m.x) * is.x, (v.y - m.y) * is.y, (v.z - m.z) * is.z, (v.w - m.w) * is.w};
+                const float4 d = ld4(dy + p * dy_ld + c);
+                float gg[4] = {d.x, d.y, d.z, d.w};
+                if (relu) {
+                    float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                    if (res) {
+                        const float4 r = ld4(res + p * res_ld + c);
+                        y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
                     }
-                    if (gout) gout[p * gout_ld + c] = g;
-                    s0 += g;
-                    s1 += g * xh;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!(y[k] > 0.f)) gg[k] = 0.f;
                 }
+                if (gout) st4(gout + p * gout_ld + c, make_float4(gg[0], gg[1], gg[2], gg[3]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s0[k] += gg[k]; s1[k] += gg[k] * xh[k]; }
             }
         }
-        red[0][row][lane] = s0;
-        red[1][row][lane] = s1;
-        __syncthreads();
-        if (row == 0 && c < C) {
-            part[((size_t)blockIdx.x * 2 + 0) * C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-            part[((size_t)blockIdx.x * 2 + 1) * C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = s0[k]; red[threadIdx.x * 8 + 4 + k] = s1[k]; }
+    __syncthreads();
+    if (row == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = 0.f;
+            for (int r = 0; r < rows; ++r) t += red[(r * G4 + g) * 8 + k];
+            const int cc = c + (k & 3);
+            if (cc < C) part[((size_t)blockIdx.x * 2 + (k >> 2)) * C + cc] = t;
         }
-        __syncthreads();
+    }
+}
+
+// Sum of the workgroups' partials of 16 channels per workgroup: thread (c = tid & 15, j = tid >> 4) adds blocks j, j+16, ...
+// in double, the 16 partial sums per channel meet in LDS.  Returns (sum a, sum b) of channel c0 + (tid & 15) to tid < 16.
+__device__ __forceinline__ void bn2_reduce16(const float* __restrict__ part, int nblk, int C, double* sh, double& s, double& ss) {
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    s = 0.0; ss = 0.0;
+    if (c < C)
+        for (int b = j; b < nblk; b += 16) {
+            s += (double)part[((size_t)b * 2 + 0) * C + c];
+            ss += (double)part[((size_t)b * 2 + 1) * C + c];
+        }
+    sh[threadIdx.x * 2] = s;
+    sh[threadIdx.x * 2 + 1] = ss;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        s = 0.0; ss = 0.0;
+        for (int k = 0; k < 16; ++k) { s += sh[(k * 16 + cl) * 2]; ss += sh[(k * 16 + cl) * 2 + 1]; }
     }
 }
 
@@ -112,13 +149,11 @@ __global__ __launch_bounds__(256) void bn2_stats_final_kernel(const float* __res
                                                               float eps, float momentum, float* __restrict__ mean,
                                                               float* __restrict__ invstd, float* __restrict__ rmean,
                                                               float* __restrict__ rvar) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((size_t)b * 2 + 0) * C + c];
-        ss += (double)part[((size_t)b * 2 + 1) * C + c];
-    }
+    __shared__ double sh[512];
+    double s, ss;
+    bn2_reduce16(part, nblk, C, sh, s, ss);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
     const double m = s / (double)npix;
     double var = ss / (double)npix - m * m;
     if (var < 0.0) var = 0.0;
@@ -149,33 +184,36 @@ __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict_
     const int g4 = out_ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= npix * g4) return;
-    const int c4 = (int)(gid % g4);
+    const int c = 4 * (int)(gid % g4);
     const long p = gid / g4;
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = 4 * c4 + k;
-        float v = 0.f;
-        if (c < C) {
-            v = (x[p * x_ld + c] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-            if (res) v += res[p * res_ld + c];
-            if (relu) v = fmaxf(v, 0.f);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        const float4 v = ld4(x + p * x_ld + c);
+        const float4 m = cpar(mean, c, C), is = cpar(invstd, c, C), ga = cpar(gamma, c, C), be = cpar(beta, c, C);
+        o = make_float4((v.x - m.x) * is.x * ga.x + be.x, (v.y - m.y) * is.y * ga.y + be.y, (v.z - m.z) * is.z * ga.z + be.z,
+                        (v.w - m.w) * is.w * ga.w + be.w);
+        if (res) {
+            const float4 r = ld4(res + p * res_ld + c);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        o[k] = v;
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (c + 3 >= C) {                                // last, partial group: padding channels stay 0
+            if (c + 1 >= C) o.y = 0.f;
+            if (c + 2 >= C) o.z = 0.f;
+            o.w = 0.f;
+        }
     }
-    st4(out + p * out_ld + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+    st4(out + p * out_ld + c, o);
 }
 
 __global__ __launch_bounds__(256) void bn2_bwd_final_kernel(const float* __restrict__ part, int nblk, int C,
                                                             float* __restrict__ sums, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((size_t)b * 2 + 0) * C + c];
-        ss += (double)part[((size_t)b * 2 + 1) * C + c];
-    }
+    __shared__ double sh[512];
+    double s, ss;
+    bn2_reduce16(part, nblk, C, sh, s, ss);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
     sums[c] = (float)s;
     sums[C + c] = (float)ss;
     dbeta[c] = (float)s;
@@ -194,29 +232,37 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
     const int g4 = dx_ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= npix * g4) return;
-    const int c4 = (int)(gid % g4);
+    const int c = 4 * (int)(gid % g4);
     const long p = gid / g4;
     const float inv_n = 1.f / (float)npix;
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = 4 * c4 + k;
-        float v = 0.f;
-        if (c < C) {
-            const float is = invstd[c], ga = gamma[c];
-            const float xh = (x[p * x_ld + c] - mean[c]) * is;
-            float gv;
-            if (g) {
-                gv = g[p * g_ld + c];
-            } else {
-                gv = dy[p * dy_ld + c];
-                if (relu && !(xh * ga + beta[c] > 0.f)) gv = 0.f;
-            }
-            v = training ? ga * is * (gv - sums[c] * inv_n - xh * sums[C + c] * inv_n) : ga * is * gv;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float4 v = ld4(x + p * x_ld + c);
+        const float4 m = cpar(mean, c, C), is4 = cpar(invstd, c, C), ga4 = cpar(gamma, c, C);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m.x, m.y, m.z, m.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+        const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+        float gv[4];
+        if (g) {
+            const float4 t = ld4(g + p * g_ld + c);
+            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+        } else {
+            const float4 t = ld4(dy + p * dy_ld + c);
+            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
         }
-        o[k] = v;
+        const float4 be4 = cpar(beta, c, C);
+        const float be[4] = {be4.x, be4.y, be4.z, be4.w};
+        const float4 sa = cpar(sums, c, C), sb = cpar(sums + C, c, C);
+        const float s1[4] = {sa.x, sa.y, sa.z, sa.w}, s2[4] = {sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c + k >= C) continue;
+            const float xh = (xv[k] - mm[k]) * is[k];
+            float gg = gv[k];
+            if (!g && relu && !(xh * ga[k] + be[k] > 0.f)) gg = 0.f;
+            o[k] = training ? ga[k] * is[k] * (gg - s1[k] * inv_n - xh * s2[k] * inv_n) : ga[k] * is[k] * gg;
+        }
     }
-    st4(dx + p * dx_ld + 4 * c4, make_float4(o[0], o[1], o[2], o[3]));
+    st4(dx + p * dx_ld + c, make_float4(o[0], o[1], o[2], o[3]));
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
@@ -731,7 +777,7 @@ size_t nvq_bn2_workspace_bytes(int C) { return (size_t)BN2_MAXBLK * 2 * (size_t)
 
 int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float momentum, float* mean, float* invstd,
                   float* running_mean, float* running_var, float* workspace, size_t workspace_bytes, void* stream) {
-    NVQ_REQUIRE(C > 0 && C <= x_ld && npix > 0, "bn2_stats: C %d ld %d", C, x_ld);
+    NVQ_REQUIRE(C > 0 && C <= 1024 && ((C + 3) & ~3) <= x_ld && x_ld % 4 == 0 && aligned16(x) && npix > 0, "bn2_stats: C %d ld %d", C, x_ld);
     NVQ_REQUIRE(workspace_bytes >= nvq_bn2_workspace_bytes(C), "bn2_stats: workspace");
     hipStream_t s = (hipStream_t)stream;
     const int nb = bn2_nblk(npix);
@@ -739,7 +785,7 @@ int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float m
                        nullptr, nullptr, 0, nullptr, 0, workspace);
     int rc = check_launch("bn2_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn2_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, workspace, nb, C, npix, eps, momentum, mean,
+    hipLaunchKernelGGL(bn2_stats_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, npix, eps, momentum, mean,
                        invstd, running_mean, running_var);
     return check_launch("bn2_stats_final");
 }
@@ -753,7 +799,8 @@ int nvq_bn2_eval_stats(const float* running_mean, const float* running_var, int 
 
 int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, const float* res, int res_ld, int relu, float* out, int out_ld, void* stream) {
-    NVQ_REQUIRE(C > 0 && C <= x_ld && C <= out_ld && out_ld % 4 == 0 && aligned16(out) && (!res || C <= res_ld),
+    NVQ_REQUIRE(C > 0 && ((C + 3) & ~3) <= x_ld && x_ld % 4 == 0 && C <= out_ld && out_ld % 4 == 0 && aligned16(out) && aligned16(x) &&
+                    (!res || (((C + 3) & ~3) <= res_ld && res_ld % 4 == 0 && aligned16(res))),
                 "bn2_apply: C %d ld %d/%d", C, x_ld, out_ld);
     hipLaunchKernelGGL(bn2_apply_kernel, dim3(blocks_for(npix * (out_ld / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, C, npix,
                        mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld);
@@ -764,8 +811,11 @@ int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C
                      const float* invstd, const float* gamma, const float* beta, const float* res, int res_ld, int relu,
                      int training, float* dx, int dx_ld, float* dres, int dres_ld, float* dgamma, float* dbeta,
                      float* workspace, size_t workspace_bytes, void* stream) {
-    NVQ_REQUIRE(C > 0 && C <= x_ld && C <= dy_ld && C <= dx_ld && dx_ld % 4 == 0 && aligned16(dx), "bn2_backward: C %d", C);
-    NVQ_REQUIRE(!res || (dres && C <= dres_ld), "bn2_backward: a residual input needs its gradient buffer");
+    const int C4 = (C + 3) & ~3;
+    NVQ_REQUIRE(C > 0 && C <= 1024 && C4 <= x_ld && C4 <= dy_ld && C4 <= dx_ld && x_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0 &&
+                    aligned16(dx) && aligned16(x) && aligned16(dy), "bn2_backward: C %d", C);
+    NVQ_REQUIRE(!res || (dres && C4 <= dres_ld && dres_ld % 4 == 0 && C4 <= res_ld && res_ld % 4 == 0 && aligned16(res) && aligned16(dres)),
+                "bn2_backward: a residual input needs its gradient buffer");
     NVQ_REQUIRE(workspace_bytes >= nvq_bn2_workspace_bytes(C) + 2 * (size_t)C * sizeof(float), "bn2_backward: workspace");
     hipStream_t s = (hipStream_t)stream;
     const int nb = bn2_nblk(npix);
@@ -774,7 +824,7 @@ int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C
                        gamma, beta, relu, dres, dres_ld, workspace);
     int rc = check_launch("bn2_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn2_bwd_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, workspace, nb, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn2_bwd_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, sums, dgamma, dbeta);
     rc = check_launch("bn2_bwd_final");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(blocks_for(npix * (dx_ld / 4))), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld,

@@ -8,9 +8,15 @@ import collections, csv, json, os, re, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-LABELS = [(r"conv_bf16_kernel<2, 3", "conv_bf16_kernel<2,3>"), (r"conv_bf16_kernel<4, 3", "conv_bf16_kernel<4,3>"),
-          (r"conv_bf16_kernel<4, 1", "conv_bf16_kernel<4,1>"), (r"wgrad_bf16_kernel<3", "wgrad_bf16_kernel<3>"),
-          (r"wgrad_bf16_kernel<1", "wgrad_bf16_kernel<1>")]
+def label_of(kernel_name: str):
+    """bench.py's label of a timed launch (nerve_cl/_nvq.py) for a rocprofv3 kernel name, or None"""
+    m = re.search(r"(conv_bf16_kernel|conv_f32_kernel)<(\d+), (\d+)", kernel_name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+    m = re.search(r"(wgrad_bf16_kernel|wgrad_f32_kernel)<(\d+)", kernel_name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    return "rdb_tail_kernel" if "rdb_tail_kernel" in kernel_name else None
 
 
 def per_kernel(path, counter):
@@ -19,17 +25,17 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        for pat, lab in LABELS:
-            if pat in r["Kernel_Name"]:
-                acc[lab].append(float(r["Counter_Value"]))
-                names.setdefault(lab, set()).add(re.sub(r"\(.*", "", r["Kernel_Name"].replace("void nvq::", "")))
+        lab = label_of(r["Kernel_Name"])
+        if lab:
+            acc[lab].append(float(r["Counter_Value"]))
+            names.setdefault(lab, set()).add(re.sub(r"\(.*", "", r["Kernel_Name"].replace("void nvq::", "")))
     return acc, names
 
 
 fetch, names = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --output-format csv -- python3 "
-                  "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer (default batch 8)",
+                  "bench.py <workload flags> --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer (tools/r2_measure.sh)",
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 "
                      "(MI355X_MICROARCH.md, HBM)", "kernels": {}}
 for lab in fetch:
