@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int relu, float* __restrict__ gout, int gout_ld,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, int bf) {
     __shared__ float red[256 * 8];
     const int G4 = (C + 3) >> 2;
     const int rows = 256 / G4;                       // pixel rows handled per iteration (G4 <= 256)
@@ -86,25 +86,25 @@ __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restric
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f), is = m, ga = m, be = m;
         if (MODE == 1) { m = cpar(mean, c, C); is = cpar(invstd, c, C); ga = cpar(gamma, c, C); be = cpar(beta, c, C); }
         for (long p = p0 + row; p < p1; p += rows) {
-            const float4 v = ld4(x + p * x_ld + c);
+            const float4 v = ldx4(x, p * x_ld + c, bf);
             if (MODE == 0) {
                 s0[0] += v.x; s0[1] += v.y; s0[2] += v.z; s0[3] += v.w;
                 s1[0] += v.x * v.x; s1[1] += v.y * v.y; s1[2] += v.z * v.z; s1[3] += v.w * v.w;
             } else {
                 const float xh[4] = {(v.x - m.x) * is.x, (v.y - m.y) * is.y, (v.z - m.z) * is.z, (v.w - m.w) * is.w};
-                const float4 d = ld4(dy + p * dy_ld + c);
+                const float4 d = ldx4(dy, p * dy_ld + c, bf);
                 float gg[4] = {d.x, d.y, d.z, d.w};
                 if (relu) {
                     float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
                     if (res) {
-                        const float4 r = ld4(res + p * res_ld + c);
+                        const float4 r = ldx4(res, p * res_ld + c, bf);
                         y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (!(y[k] > 0.f)) gg[k] = 0.f;
                 }
-                if (gout) st4(gout + p * gout_ld + c, make_float4(gg[0], gg[1], gg[2], gg[3]));
+                if (gout) stx4(gout, p * gout_ld + c, bf, make_float4(gg[0], gg[1], gg[2], gg[3]));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s0[k] += gg[k]; s1[k] += gg[k] * xh[k]; }
             }
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ res, int res_ld, int relu,
-                                                        float* __restrict__ out, int out_ld) {
+                                                        float* __restrict__ out, int out_ld, int bf) {
     const int g4 = out_ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= npix * g4) return;
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict_
     const long p = gid / g4;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        const float4 v = ld4(x + p * x_ld + c);
+        const float4 v = ldx4(x, p * x_ld + c, bf);
         const float4 m = cpar(mean, c, C), is = cpar(invstd, c, C), ga = cpar(gamma, c, C), be = cpar(beta, c, C);
         o = make_float4((v.x - m.x) * is.x * ga.x + be.x, (v.y - m.y) * is.y * ga.y + be.y, (v.z - m.z) * is.z * ga.z + be.z,
                         (v.w - m.w) * is.w * ga.w + be.w);
         if (res) {
-            const float4 r = ld4(res + p * res_ld + c);
+            const float4 r = ldx4(res, p * res_ld + c, bf);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict_
             o.w = 0.f;
         }
     }
-    st4(out + p * out_ld + c, o);
+    stx4(out, p * out_ld + c, bf, o);
 }
 
 __global__ __launch_bounds__(256) void bn2_bwd_final_kernel(const float* __restrict__ part, int nblk, int C,
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ sums, int relu, int training,
-                                                            float* __restrict__ dx, int dx_ld) {
+                                                            float* __restrict__ dx, int dx_ld, int bf) {
     const int g4 = dx_ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= npix * g4) return;
@@ -237,16 +237,16 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
     const float inv_n = 1.f / (float)npix;
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const float4 v = ld4(x + p * x_ld + c);
+        const float4 v = ldx4(x, p * x_ld + c, bf);
         const float4 m = cpar(mean, c, C), is4 = cpar(invstd, c, C), ga4 = cpar(gamma, c, C);
         const float xv[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m.x, m.y, m.z, m.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
         const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
         float gv[4];
         if (g) {
-            const float4 t = ld4(g + p * g_ld + c);
+            const float4 t = ldx4(g, p * g_ld + c, bf);
             gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
         } else {
-            const float4 t = ld4(dy + p * dy_ld + c);
+            const float4 t = ldx4(dy, p * dy_ld + c, bf);
             gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
         }
         const float4 be4 = cpar(beta, c, C);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
             o[k] = training ? ga[k] * is[k] * (gg - s1[k] * inv_n - xh * s2[k] * inv_n) : ga[k] * is[k] * gg;
         }
     }
-    st4(dx + p * dx_ld + c, make_float4(o[0], o[1], o[2], o[3]));
+    stx4(dx, p * dx_ld + c, bf, make_float4(o[0], o[1], o[2], o[3]));
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
 // the image are skipped.  idx[n, oy, ox, c] = ky * k + kx of the winner (one byte).
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int ld, int H, int W, int OH, int OW,
                                                           int k, int s, int pad, long total, float* __restrict__ out,
-                                                          uint8_t* __restrict__ idx) {
+                                                          uint8_t* __restrict__ idx, int bf) {
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         for (int kx = 0; kx < k; ++kx) {
             const int ix = ox * s - pad + kx;
             if (ix < 0 || ix >= W) continue;
-            const float4 v = ld4(x + ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4);
+            const float4 v = ldx4(x, ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, bf);
             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         }
     }
     const size_t o = ((size_t)(n * OH + oy) * OW + ox) * ld + 4 * c4;
-    st4(out + o, make_float4(best[0], best[1], best[2], best[3]));
+    stx4(out, o, bf, make_float4(best[0], best[1], best[2], best[3]));
     *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
 }
 
 // gather form: every input pixel collects dy of the windows it won (fixed order, no atomics)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           int ld, int H, int W, int OH, int OW, int k, int s, int pad,
-                                                          long total, float* __restrict__ dx) {
+                                                          long total, float* __restrict__ dx, int bf) {
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -327,19 +327,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
             const int me = (iy - (oy * s - pad)) * k + (ix - (ox * s - pad));
             const size_t o = ((size_t)(n * OH + oy) * OW + ox) * ld + 4 * c4;
             const uchar4 w = *reinterpret_cast<const uchar4*>(idx + o);
-            const float4 g = ld4(dy + o);
+            const float4 g = ldx4(dy, o, bf);
             if (w.x == me) acc[0] += g.x;
             if (w.y == me) acc[1] += g.y;
             if (w.z == me) acc[2] += g.z;
             if (w.w == me) acc[3] += g.w;
         }
-    st4(dx + ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    stx4(dx, ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, bf, make_float4(acc[0], acc[1], acc[2], acc[3]));
 }
 
 // ------------------------------------------------------------------------------------------------ stride-2 subsampling
 // forward: out[n, y, x] = in[n, 2y, 2x]  (the input side of a 1x1 stride-2 convolution); backward: zero-insertion.
 __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ in, int ld, int H, int W, int OH, int OW,
-                                                         long total, float* __restrict__ out, int backward) {
+                                                         long total, float* __restrict__ out, int backward, int bf) {
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -350,16 +350,16 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict
         q /= OW;
         const int oy = (int)(q % OH);
         const int n = (int)(q / OH);
-        st4(out + ((size_t)(n * OH + oy) * OW + ox) * ld + 4 * c4,
-            ld4(in + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ld + 4 * c4));
+        stx4(out, ((size_t)(n * OH + oy) * OW + ox) * ld + 4 * c4, bf,
+             ldx4(in, ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ld + 4 * c4, bf));
     } else {            // `in` = gradient at [OH, OW], `out` = gradient at [H, W]
         const int ix = (int)(q % W);
         q /= W;
         const int iy = (int)(q % H);
         const int n = (int)(q / H);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(iy & 1) && !(ix & 1)) v = ld4(in + ((size_t)(n * OH + (iy >> 1)) * OW + (ix >> 1)) * ld + 4 * c4);
-        st4(out + ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, v);
+        if (!(iy & 1) && !(ix & 1)) v = ldx4(in, ((size_t)(n * OH + (iy >> 1)) * OW + (ix >> 1)) * ld + 4 * c4, bf);
+        stx4(out, ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, bf, v);
     }
 }
 
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------ depth <-> space (block 2)
 // to_space: out[n, 2y+py, 2x+px, c] = in[n, y, x, (py*2+px)*Co + c]; to_depth: the inverse.  Co % 4 == 0.
 __global__ __launch_bounds__(256) void depth_space2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
-                                                           int Co, long total, int to_depth) {
+                                                           int Co, long total, int to_depth, int bf) {
     const int g4 = Co >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;                       // total = N * 2H * 2W * g4
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void depth_space2_kernel(const float* __restri
     const int n = (int)(q / (2 * H));
     const size_t deep = ((size_t)(n * H + (Y >> 1)) * W + (X >> 1)) * (4 * Co) + (size_t)(((Y & 1) * 2 + (X & 1)) * Co) + 4 * c4;
     const size_t wide = ((size_t)(n * 2 * H + Y) * (2 * W) + X) * Co + 4 * c4;
-    if (to_depth) st4(out + deep, ld4(in + wide));
-    else st4(out + wide, ld4(in + deep));
+    if (to_depth) stx4(out, deep, bf, ldx4(in, wide, bf));
+    else stx4(out, wide, bf, ldx4(in, deep, bf));
 }
 
 // ConvTranspose2d(k=4, s=2, p=1) weight [Ci, Co, 4, 4]  <->  3x3 conv weight [4*Co, Ci, 3, 3] (output-phase major):
@@ -534,6 +534,25 @@ __global__ __launch_bounds__(256) void add_image_channel_kernel(float* __restric
     const float4 b = ld4(v + (size_t)n * C + 4 * c4);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     st4(x + p * ld + 4 * c4, a);
+}
+
+// dst[p, dst_coff + c] (+)= alpha * src[p, src_coff + c] for c < C (C % 4 == 0), either side fp32 or bf16: the storage-type
+// boundary between the bf16 stages of FrameRecoveryNet and its fp32 attention / fusion stages, and mean / broadcast over time
+__global__ __launch_bounds__(256) void cast_slice_kernel(float* __restrict__ dst, int dst_ld, int dst_coff, int dst_bf,
+                                                         const float* __restrict__ src, int src_ld, int src_coff, int src_bf,
+                                                         int C, long total, float alpha, int accumulate) {
+    const int g4 = C >> 2;
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;
+    const int c = 4 * (int)(gid % g4);
+    const long p = gid / g4;
+    float4 v = ldx4(src, p * src_ld + src_coff + c, src_bf);
+    v = make_float4(alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w);
+    if (accumulate) {
+        const float4 o = ldx4(dst, p * dst_ld + dst_coff + c, dst_bf);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    stx4(dst, p * dst_ld + dst_coff + c, dst_bf, v);
 }
 
 // y = tanh(x) | dx = dy * (1 - y^2), over whole rows (ld floats per pixel; padding channels stay 0)
@@ -635,7 +654,8 @@ __global__ __launch_bounds__(256) void mask_blend_bwd_kernel(const float* __rest
 constexpr int ST_T = 8, ST_P = 2 * ST_T + 5;        // 21
 
 __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int H, int W,
-                                                        int OH, int OW, int Co, int tilesX, float* __restrict__ out, int out_ld) {
+                                                        int OH, int OW, int Co, int tilesX, float* __restrict__ out, int out_ld,
+                                                        int out_bf) {
     extern __shared__ float smem[];
     float* patch = smem;                             // [21*21][4]
     float* wl = smem + ST_P * ST_P * 4;              // [196][64]
@@ -679,10 +699,11 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
             }
         const int oy = oy0 + py_, ox = ox0 + px_;
         if (oy < OH && ox < OW) {
-            float* o = out + ((size_t)(n * OH + oy) * OW + ox) * out_ld + co0 + cg * 16;
+            const size_t o = ((size_t)(n * OH + oy) * OW + ox) * out_ld + co0 + cg * 16;
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4)
-                if (co0 + cg * 16 + 4 * j4 < Co) st4(o + 4 * j4, make_float4(acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]));
+                if (co0 + cg * 16 + 4 * j4 < Co)
+                    stx4(out, o + 4 * j4, out_bf, make_float4(acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]));
         }
     }
 }
@@ -692,7 +713,7 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
 // slabs [workgroup][co][196] are summed by launch_reduce_partials in a fixed order.
 __global__ __launch_bounds__(256) void stem7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dy_ld,
                                                           int N, int H, int W, int OH, int OW, int Co, int co0, int tilesX,
-                                                          int tilesY, float* __restrict__ part) {
+                                                          int tilesY, float* __restrict__ part, int dy_bf) {
     __shared__ float patch[ST_P * ST_P * 4];
     __shared__ float dtile[ST_T * ST_T][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -714,7 +735,12 @@ __global__ __launch_bounds__(256) void stem7_wgrad_kernel(const float* __restric
         for (int i = threadIdx.x; i < ST_T * ST_T * 64; i += 256) {
             const int co = i & 63, p = i >> 6;
             const int oy = oy0 + p / ST_T, ox = ox0 + p % ST_T;
-            dtile[p][co] = (oy < OH && ox < OW && co0 + co < Co) ? dy[((size_t)(n * OH + oy) * OW + ox) * dy_ld + co0 + co] : 0.f;
+            float dv = 0.f;
+            if (oy < OH && ox < OW && co0 + co < Co) {
+                const size_t e = ((size_t)(n * OH + oy) * OW + ox) * dy_ld + co0 + co;
+                dv = dy_bf ? (float)reinterpret_cast<const __bf16*>(dy)[e] : dy[e];
+            }
+            dtile[p][co] = dv;
         }
         __syncthreads();
         for (int p = 0; p < ST_T * ST_T; ++p) {
@@ -776,13 +802,13 @@ static int bn2_nblk(long npix) {
 size_t nvq_bn2_workspace_bytes(int C) { return (size_t)BN2_MAXBLK * 2 * (size_t)C * sizeof(float); }
 
 int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float momentum, float* mean, float* invstd,
-                  float* running_mean, float* running_var, float* workspace, size_t workspace_bytes, void* stream) {
+                  float* running_mean, float* running_var, float* workspace, size_t workspace_bytes, int bf16, void* stream) {
     NVQ_REQUIRE(C > 0 && C <= 1024 && ((C + 3) & ~3) <= x_ld && x_ld % 4 == 0 && aligned16(x) && npix > 0, "bn2_stats: C %d ld %d", C, x_ld);
     NVQ_REQUIRE(workspace_bytes >= nvq_bn2_workspace_bytes(C), "bn2_stats: workspace");
     hipStream_t s = (hipStream_t)stream;
     const int nb = bn2_nblk(npix);
     hipLaunchKernelGGL(bn2_partial_kernel<0>, dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                       nullptr, nullptr, 0, nullptr, 0, workspace);
+                       nullptr, nullptr, 0, nullptr, 0, workspace, bf16);
     int rc = check_launch("bn2_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_stats_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, npix, eps, momentum, mean,
@@ -798,19 +824,19 @@ int nvq_bn2_eval_stats(const float* running_mean, const float* running_var, int 
 }
 
 int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean, const float* invstd, const float* gamma,
-                  const float* beta, const float* res, int res_ld, int relu, float* out, int out_ld, void* stream) {
+                  const float* beta, const float* res, int res_ld, int relu, float* out, int out_ld, int bf16, void* stream) {
     NVQ_REQUIRE(C > 0 && ((C + 3) & ~3) <= x_ld && x_ld % 4 == 0 && C <= out_ld && out_ld % 4 == 0 && aligned16(out) && aligned16(x) &&
                     (!res || (((C + 3) & ~3) <= res_ld && res_ld % 4 == 0 && aligned16(res))),
                 "bn2_apply: C %d ld %d/%d", C, x_ld, out_ld);
     hipLaunchKernelGGL(bn2_apply_kernel, dim3(blocks_for(npix * (out_ld / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, C, npix,
-                       mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld);
+                       mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld, bf16);
     return check_launch("bn2_apply");
 }
 
 int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C, long npix, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, const float* res, int res_ld, int relu,
                      int training, float* dx, int dx_ld, float* dres, int dres_ld, float* dgamma, float* dbeta,
-                     float* workspace, size_t workspace_bytes, void* stream) {
+                     float* workspace, size_t workspace_bytes, int bf16, void* stream) {
     const int C4 = (C + 3) & ~3;
     NVQ_REQUIRE(C > 0 && C <= 1024 && C4 <= x_ld && C4 <= dy_ld && C4 <= dx_ld && x_ld % 4 == 0 && dy_ld % 4 == 0 && dx_ld % 4 == 0 &&
                     aligned16(dx) && aligned16(x) && aligned16(dy), "bn2_backward: C %d", C);
@@ -821,44 +847,44 @@ int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C
     const int nb = bn2_nblk(npix);
     float* sums = workspace + (size_t)BN2_MAXBLK * 2 * C;
     hipLaunchKernelGGL(bn2_partial_kernel<1>, dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld, res, res_ld, mean, invstd,
-                       gamma, beta, relu, dres, dres_ld, workspace);
+                       gamma, beta, relu, dres, dres_ld, workspace, bf16);
     int rc = check_launch("bn2_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_bwd_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, sums, dgamma, dbeta);
     rc = check_launch("bn2_bwd_final");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(blocks_for(npix * (dx_ld / 4))), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld,
-                       dres, dres_ld, mean, invstd, gamma, beta, sums, relu, training, dx, dx_ld);
+                       dres, dres_ld, mean, invstd, gamma, beta, sums, relu, training, dx, dx_ld, bf16);
     return check_launch("bn2_bwd_apply");
 }
 
 int nvq_maxpool_forward(const float* x, int ld, int N, int H, int W, int k, int s, int pad, float* out, uint8_t* idx,
-                        void* stream) {
+                        int bf16, void* stream) {
     NVQ_REQUIRE(ld % 4 == 0 && k >= 1 && k <= 7 && s >= 1 && pad * 2 <= k && aligned16(x) && aligned16(out), "maxpool_forward: args");
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     NVQ_REQUIRE(OH > 0 && OW > 0, "maxpool_forward: empty output");
     const long total = (long)N * OH * OW * (ld / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, H, W, OH, OW, k, s, pad,
-                       total, out, idx);
+                       total, out, idx, bf16);
     return check_launch("maxpool_forward");
 }
 
 int nvq_maxpool_backward(const float* dy, const uint8_t* idx, int ld, int N, int H, int W, int k, int s, int pad, float* dx,
-                         void* stream) {
+                         int bf16, void* stream) {
     NVQ_REQUIRE(ld % 4 == 0 && k >= 1 && k <= 7 && s >= 1 && pad * 2 <= k, "maxpool_backward: args");
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     const long total = (long)N * H * W * (ld / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, ld, H, W, OH, OW, k, s,
-                       pad, total, dx);
+                       pad, total, dx, bf16);
     return check_launch("maxpool_backward");
 }
 
-int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int backward, void* stream) {
+int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int backward, int bf16, void* stream) {
     NVQ_REQUIRE(ld % 4 == 0 && N > 0 && H > 0 && W > 0, "subsample2: args");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const long total = backward ? (long)N * H * W * (ld / 4) : (long)N * OH * OW * (ld / 4);
     hipLaunchKernelGGL(subsample2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, ld, H, W, OH, OW, total, out,
-                       backward);
+                       backward, bf16);
     return check_launch("subsample2");
 }
 
@@ -877,11 +903,11 @@ int nvq_bilinear_resize(const float* in, int ld, int N, int H, int W, int OH, in
     return check_launch("bilinear_resize");
 }
 
-int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, void* stream) {
+int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, int bf16, void* stream) {
     NVQ_REQUIRE(Co % 4 == 0 && N > 0 && H > 0 && W > 0, "depth_space2: Co %d", Co);
     const long total = (long)N * 2 * H * 2 * W * (Co / 4);
     hipLaunchKernelGGL(depth_space2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, Co, total,
-                       to_depth);
+                       to_depth, bf16);
     return check_launch("depth_space2");
 }
 
@@ -921,6 +947,16 @@ int nvq_add_image_channel(float* x, int ld, int C, int N, int H, int W, const fl
     hipLaunchKernelGGL(add_image_channel_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, C, (long)H * W,
                        total, v);
     return check_launch("add_image_channel");
+}
+
+int nvq_cast_slice(float* dst, int dst_ld, int dst_coff, int dst_bf16, const float* src, int src_ld, int src_coff, int src_bf16,
+                   int C, long npix, float alpha, int accumulate, void* stream) {
+    NVQ_REQUIRE(C > 0 && C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && src_ld % 4 == 0 && src_coff % 4 == 0 &&
+                    dst_coff + C <= dst_ld && src_coff + C <= src_ld, "cast_slice: C %d ld %d/%d", C, dst_ld, src_ld);
+    const long total = npix * (C / 4);
+    hipLaunchKernelGGL(cast_slice_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, dst_coff, dst_bf16,
+                       src, src_ld, src_coff, src_bf16, C, total, alpha, accumulate);
+    return check_launch("cast_slice");
 }
 
 int nvq_tanh(const float* a, const float* y, long n, float* out, int backward, void* stream) {
@@ -965,17 +1001,19 @@ int nvq_mask_blend_backward(const float* dout, const float* mask, int N, int C, 
     return check_launch("mask_blend_backward");
 }
 
-int nvq_stem7_forward(const float* x, const float* w, int N, int H, int W, int Co, float* out, int out_ld, void* stream) {
+int nvq_stem7_forward(const float* x, const float* w, int N, int H, int W, int Co, float* out, int out_ld, int out_bf16,
+                      void* stream) {
     NVQ_REQUIRE(Co > 0 && Co % 4 == 0 && Co <= out_ld && aligned16(x) && aligned16(out) && out_ld % 4 == 0, "stem7_forward: Co %d", Co);
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
     const int tx = ceil_div(OW, ST_T), ty = ceil_div(OH, ST_T);
     const size_t lds = (size_t)(ST_P * ST_P * 4 + 196 * 64) * sizeof(float);
-    hipLaunchKernelGGL(stem7_fwd_kernel, dim3(tx * ty, N), dim3(256), lds, (hipStream_t)stream, x, w, H, W, OH, OW, Co, tx, out, out_ld);
+    hipLaunchKernelGGL(stem7_fwd_kernel, dim3(tx * ty, N), dim3(256), lds, (hipStream_t)stream, x, w, H, W, OH, OW, Co, tx, out, out_ld,
+                       out_bf16);
     return check_launch("stem7_forward");
 }
 
 int nvq_stem7_wgrad(const float* x, const float* dy, int dy_ld, int N, int H, int W, int Co, float* dw, float* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    size_t workspace_bytes, int dy_bf16, void* stream) {
     NVQ_REQUIRE(Co > 0 && Co <= dy_ld && aligned16(x), "stem7_wgrad: Co %d", Co);
     const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
     const int tx = ceil_div(OW, ST_T), ty = ceil_div(OH, ST_T);
@@ -984,7 +1022,8 @@ int nvq_stem7_wgrad(const float* x, const float* dy, int dy_ld, int N, int H, in
     NVQ_REQUIRE(workspace_bytes >= (size_t)nblk * 64 * 196 * sizeof(float), "stem7_wgrad: workspace");
     hipStream_t s = (hipStream_t)stream;
     for (int co0 = 0; co0 < Co; co0 += 64) {
-        hipLaunchKernelGGL(stem7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, dy_ld, N, H, W, OH, OW, Co, co0, tx, ty, workspace);
+        hipLaunchKernelGGL(stem7_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, dy_ld, N, H, W, OH, OW, Co, co0, tx, ty, workspace,
+                           dy_bf16);
         int rc = check_launch("stem7_wgrad");
         if (rc) return rc;
         const int cn = Co - co0 < 64 ? Co - co0 : 64;

@@ -111,17 +111,18 @@ SIGNATURES = {
     "nvq_nchw_to_nhwc": (ci, [vp, cl, ci, ci, ci, ci, vp, ci, ci, ci, vp]),
     "nvq_nhwc_to_nchw": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, cl, vp]),
     "nvq_bn2_workspace_bytes": (sz, [ci]),
-    "nvq_bn2_stats": (ci, [vp, ci, ci, cl, cf, cf, vp, vp, vp, vp, vp, sz, vp]),
+    "nvq_bn2_stats": (ci, [vp, ci, ci, cl, cf, cf, vp, vp, vp, vp, vp, sz, ci, vp]),
     "nvq_bn2_eval_stats": (ci, [vp, vp, ci, cf, vp, vp, vp]),
-    "nvq_bn2_apply": (ci, [vp, ci, ci, cl, vp, vp, vp, vp, vp, ci, ci, vp, ci, vp]),
-    "nvq_bn2_backward": (ci, [vp, ci, vp, ci, ci, cl, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]),
-    "nvq_maxpool_forward": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
-    "nvq_maxpool_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
-    "nvq_subsample2": (ci, [vp, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_bn2_apply": (ci, [vp, ci, ci, cl, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp]),
+    "nvq_bn2_backward": (ci, [vp, ci, vp, ci, ci, cl, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, sz, ci, vp]),
+    "nvq_maxpool_forward": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp]),
+    "nvq_maxpool_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_subsample2": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp]),
     "nvq_bilinear_resize": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_convt_pack": (ci, [vp, ci, ci, vp, vp]),
     "nvq_convt_unpack_grad": (ci, [vp, ci, ci, vp, vp]),
-    "nvq_depth_space2": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "nvq_depth_space2": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "nvq_cast_slice": (ci, [vp, ci, ci, ci, vp, ci, ci, ci, ci, cl, cf, ci, vp]),
     "nvq_tconv_relayout": (ci, [vp, vp, ci, ci, ci, vp]),
     "nvq_gap_blocks": (ci, [ci, ci]),
     "nvq_gap_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
@@ -131,8 +132,8 @@ SIGNATURES = {
     "nvq_fusion_mix_backward": (ci, [vp, vp, vp, ci, cl, vp, ci, vp, ci, vp, ci, vp]),
     "nvq_mask_blend": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
     "nvq_mask_blend_backward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp]),
-    "nvq_stem7_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp]),
-    "nvq_stem7_wgrad": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, sz, vp]),
+    "nvq_stem7_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp]),
+    "nvq_stem7_wgrad": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]),
     "nvq_pixel_shuffle": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_mse_forward": (ci, [vp, vp, cl, vp, vp, sz, vp]),
     "nvq_mse_backward": (ci, [vp, vp, cl, vp, vp, vp]),

@@ -6,7 +6,9 @@ autograd only chains them.  They are what ``FrameRecoveryNet`` is assembled from
 modules (``DepthwiseSeparableConv``, ``PixelShuffleUpsampler``, ``ResidualBlock``, ``CBAM``, ``TemporalConv3D``) a working
 ``forward`` on HIP tensors.  (``SuperResolutionNet`` does not use them: its schedule is hand-fused in ``_engine.py``.)
 
-Convention: activations are fp32 ``[N, H, W, ld]`` (NHWC) with ``ld = pad4(C)``; channels ``[C, ld)`` are zero.
+Convention: activations are ``[N, H, W, ld]`` (NHWC), fp32 with ``ld = pad4(C)`` or - the storage type of
+FrameRecoveryNet's high-resolution stages in the bf16 mode - bf16 with ``ld = pad8(C)``; channels ``[C, ld)`` are zero.
+An op's output has its input's storage type unless it takes an ``out_dtype``; the attention / fusion ops are fp32 only.
 There is no CPU path: every function raises on non-HIP tensors.
 """
 from __future__ import annotations
@@ -28,6 +30,41 @@ def _new(like: torch.Tensor, *shape, dtype=torch.float32, zero=False) -> torch.T
 
 def _ws(t: torch.Tensor) -> torch.Tensor:
     return _engine.workspace(t.device)
+
+
+def padc(c: int, dtype) -> int:
+    """stored channel count of a C-channel activation: 16-byte multiples"""
+    return (c + 7) // 8 * 8 if dtype == torch.bfloat16 else pad4(c)
+
+
+def _bf(t: torch.Tensor) -> int:
+    return int(t.dtype == torch.bfloat16)
+
+
+def cast_slice_(dst: torch.Tensor, src: torch.Tensor, C: int, dst_coff: int = 0, src_coff: int = 0, alpha: float = 1.0,
+                accumulate: bool = False) -> None:
+    """dst[..., dst_coff:+C] (+)= alpha * src[..., src_coff:+C]; either side fp32 or bf16"""
+    npix = dst.numel() // dst.shape[-1]
+    check(lib().nvq_cast_slice(ptr(dst), dst.shape[-1], dst_coff, _bf(dst), ptr(src), src.shape[-1], src_coff, _bf(src), C, npix,
+                               alpha, int(accumulate), stream()), "nvq_cast_slice")
+
+
+class Cast(torch.autograd.Function):
+    """storage-type change of an activation (bf16 <-> fp32), channel padding re-sized"""
+
+    @staticmethod
+    def forward(ctx, x, dtype, C: int):
+        ctx.src_dtype, ctx.C = x.dtype, C
+        if x.dtype == dtype:
+            return x.view_as(x)
+        N, H, W, _ = x.shape
+        y = _new(x, N, H, W, padc(C, dtype), dtype=dtype, zero=padc(C, dtype) > pad4(C))
+        cast_slice_(y, x, pad4(C))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return Cast.apply(dy.contiguous(), ctx.src_dtype, ctx.C), None, None
 
 
 # ----------------------------------------------------------------------------- layout
@@ -70,18 +107,30 @@ class ToNCHW(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- convolutions
+def _wgrad(x, Ci: int, g, Co: int, wshape, has_bias: bool, k: int, math: int):
+    """weight (and bias) gradient of a stride-1 conv: x [.., ld], g = dy [.., ldg] with Co real channels.  A bf16 dy is
+    handed over with its whole (8-channel aligned, zero padded) width - the kernels want 16-byte channel groups - and the
+    first Co rows of the result are returned."""
+    Cg = g.shape[-1] if g.dtype == torch.bfloat16 else Co
+    full = _new(x, Cg, *wshape[1:])
+    db = _new(x, Cg) if has_bias else None
+    K.conv_wgrad(Sl(x), Ci, Sl(g, Cg), full, db, _ws(x), k, math=math)
+    return full[:Co], (db[:Co] if has_bias else None)
+
+
 class Conv(torch.autograd.Function):
     """nn.Conv2d(k in {1,3}, stride 1, 'same' padding) (+ bias) (+ ReLU) through the implicit-GEMM MFMA kernels.
     weight [Co, Ci, k, k] with Ci <= x.ld; output [N,H,W,pad4(Co)]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu: bool, math: int):
+    def forward(ctx, x, weight, bias, relu: bool, math: int, out_dtype=None):
         N, H, W, ld = x.shape
         Co, Ci, k, _ = weight.shape
-        assert Ci <= ld and ld % 4 == 0
-        y = _new(x, N, H, W, pad4(Co))
+        dt = x.dtype if out_dtype is None else out_dtype
+        assert Ci <= ld and ld % 4 == 0 and not (relu and dt != torch.float32)
+        y = _new(x, N, H, W, padc(Co, dt), dtype=dt)
         wp = K.conv_pack(weight, False, ld, math=math)
-        K.conv_forward(Sl(x), wp, bias, Sl(y, Co), k, relu=relu, cout_store=pad4(Co), math=math)
+        K.conv_forward(Sl(x), wp, bias, Sl(y, Co), k, relu=relu, cout_store=y.shape[-1], math=math)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.relu, ctx.math, ctx.has_bias = relu, math, bias is not None
         return y
@@ -97,15 +146,13 @@ class Conv(torch.autograd.Function):
             K.axpy_slice(Sl(g), Sl(dy), 1.0, accumulate=False, mask=Sl(y))
         else:
             g = dy
-        dw = torch.empty_like(weight)
-        db = _new(x, Co) if ctx.has_bias else None
-        K.conv_wgrad(Sl(x), Ci, Sl(g, Co), dw, db, _ws(x), k, math=ctx.math)
+        dw, db = _wgrad(x, Ci, g, Co, weight.shape, ctx.has_bias, k, ctx.math)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wt = K.conv_pack(weight, True, g.shape[-1], Ci, math=ctx.math)
             K.conv_forward(Sl(g), wt, None, Sl(dx, Ci), k, cout_store=ld, math=ctx.math)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class DwConv(torch.autograd.Function):
@@ -143,13 +190,15 @@ class TemporalConv(torch.autograd.Function):
         Co, Ci = weight.shape[:2]
         taps = _new(x, 3, Co, Ci, 1, 1)
         check(lib().nvq_tconv_relayout(ptr(weight), ptr(taps), Co, Ci, 1, stream()), "nvq_tconv_relayout")
-        y = _new(x, NB, H, W, pad4(Co))
+        y = _new(x, NB, H, W, padc(Co, x.dtype), dtype=x.dtype)
         xs, ys = Sl(x), Sl(y, Co)
         packs = [K.conv_pack(taps[k], False, ld, math=math) for k in range(3)]
-        K.conv_forward(xs, packs[1], None, ys, 1, cout_store=pad4(Co), math=math)
+        K.conv_forward(xs, packs[1], None, ys, 1, cout_store=y.shape[-1], math=math)
         if T > 1:
-            K.conv_forward(xs.images(0, NB - B), packs[0], None, ys.images(B, NB), 1, accumulate=True, math=math)
-            K.conv_forward(xs.images(B, NB), packs[2], None, ys.images(0, NB - B), 1, accumulate=True, math=math)
+            K.conv_forward(xs.images(0, NB - B), packs[0], None, ys.images(B, NB), 1, accumulate=True, cout_store=y.shape[-1],
+                           math=math)
+            K.conv_forward(xs.images(B, NB), packs[2], None, ys.images(0, NB - B), 1, accumulate=True, cout_store=y.shape[-1],
+                           math=math)
         ctx.save_for_backward(x, taps)
         ctx.T, ctx.math, ctx.wshape = T, math, weight.shape
         return y
@@ -162,6 +211,7 @@ class TemporalConv(torch.autograd.Function):
         B = NB // T
         Co, Ci = taps.shape[1:3]
         dy = dy.contiguous()
+        assert dy.dtype == torch.float32 or Co % 8 == 0
         xs, gs = Sl(x), Sl(dy, Co)
         dtaps = _new(x, 3, Co, Ci, 1, 1, zero=(T == 1))
         ws = _ws(x)
@@ -180,8 +230,8 @@ class TemporalConv(torch.autograd.Function):
             K.conv_forward(gfull, tp[1], None, dxs, 1, cout_store=ld, math=math)
             if T > 1:
                 # x[t] fed out[t+1] through W0 and out[t-1] through W2
-                K.conv_forward(gfull.images(B, NB), tp[0], None, dxs.images(0, NB - B), 1, accumulate=True, math=math)
-                K.conv_forward(gfull.images(0, NB - B), tp[2], None, dxs.images(B, NB), 1, accumulate=True, math=math)
+                K.conv_forward(gfull.images(B, NB), tp[0], None, dxs.images(0, NB - B), 1, accumulate=True, cout_store=ld, math=math)
+                K.conv_forward(gfull.images(0, NB - B), tp[2], None, dxs.images(B, NB), 1, accumulate=True, cout_store=ld, math=math)
         return dx, dw, None, None
 
 
@@ -196,10 +246,11 @@ class ConvT(torch.autograd.Function):
         assert Co % 4 == 0 and Ci <= ld
         w3 = _new(x, 4 * Co, Ci, 3, 3)
         check(lib().nvq_convt_pack(ptr(weight), Ci, Co, ptr(w3), stream()), "nvq_convt_pack")
-        u = _new(x, N, H, W, 4 * Co)
+        assert x.dtype == torch.float32 or Co % 8 == 0
+        u = _new(x, N, H, W, 4 * Co, dtype=x.dtype)
         K.conv_forward(Sl(x), K.conv_pack(w3, False, ld, math=math), None, Sl(u), 3, math=math)
-        y = _new(x, N, 2 * H, 2 * W, Co)
-        check(lib().nvq_depth_space2(ptr(u), ptr(y), N, H, W, Co, 0, stream()), "nvq_depth_space2")
+        y = _new(x, N, 2 * H, 2 * W, Co, dtype=x.dtype)
+        check(lib().nvq_depth_space2(ptr(u), ptr(y), N, H, W, Co, 0, _bf(x), stream()), "nvq_depth_space2")
         ctx.save_for_backward(x, w3)
         ctx.math, ctx.wshape = math, weight.shape
         return y
@@ -211,8 +262,8 @@ class ConvT(torch.autograd.Function):
         N, H, W, ld = x.shape
         Ci, Co = ctx.wshape[:2]
         dy = dy.contiguous()
-        du = _new(x, N, H, W, 4 * Co)
-        check(lib().nvq_depth_space2(ptr(dy), ptr(du), N, H, W, Co, 1, stream()), "nvq_depth_space2")
+        du = _new(x, N, H, W, 4 * Co, dtype=dy.dtype)
+        check(lib().nvq_depth_space2(ptr(dy), ptr(du), N, H, W, Co, 1, _bf(dy), stream()), "nvq_depth_space2")
         dw3 = torch.empty_like(w3)
         K.conv_wgrad(Sl(x), Ci, Sl(du), dw3, None, _ws(x), 3, math=math)
         dw = _new(x, *ctx.wshape)
@@ -228,13 +279,13 @@ class Stem7(torch.autograd.Function):
     """nn.Conv2d(4, Co, 7, 2, 3, bias=False) on a 4-channel NHWC image (frame_recovery.py:42-44); the image carries no gradient"""
 
     @staticmethod
-    def forward(ctx, x4, weight):
+    def forward(ctx, x4, weight, out_dtype=torch.float32):
         N, H, W, c = x4.shape
         Co = weight.shape[0]
-        assert c == 4 and tuple(weight.shape[1:]) == (4, 7, 7) and Co % 4 == 0
+        assert c == 4 and tuple(weight.shape[1:]) == (4, 7, 7) and Co % 8 == 0
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = _new(x4, N, OH, OW, Co)
-        check(lib().nvq_stem7_forward(ptr(x4), ptr(weight), N, H, W, Co, ptr(y), Co, stream()), "nvq_stem7_forward")
+        y = _new(x4, N, OH, OW, Co, dtype=out_dtype)
+        check(lib().nvq_stem7_forward(ptr(x4), ptr(weight), N, H, W, Co, ptr(y), Co, _bf(y), stream()), "nvq_stem7_forward")
         ctx.save_for_backward(x4)
         ctx.wshape = weight.shape
         return y
@@ -247,8 +298,8 @@ class Stem7(torch.autograd.Function):
         dw = _new(x4, *ctx.wshape)
         ws = _ws(x4)
         check(lib().nvq_stem7_wgrad(ptr(x4), ptr(dy), dy.shape[-1], N, H, W, ctx.wshape[0], ptr(dw), ptr(ws), ws.numel() * 4,
-                                    stream()), "nvq_stem7_wgrad")
-        return None, dw
+                                    _bf(dy), stream()), "nvq_stem7_wgrad")
+        return None, dw, None
 
 
 # ----------------------------------------------------------------------------- BatchNorm (+ residual) (+ ReLU)
@@ -262,16 +313,17 @@ class BatchNorm(torch.autograd.Function):
         N, H, W, ld = x.shape
         C = gamma.numel()
         npix = N * H * W
+        assert res is None or res.dtype == x.dtype
         mean, invstd = _new(x, C), _new(x, C)
         ws = _ws(x)
         if training:
             check(lib().nvq_bn2_stats(ptr(x), ld, C, npix, BN_EPS, BN_MOMENTUM, ptr(mean), ptr(invstd), ptr(rmean), ptr(rvar),
-                                      ptr(ws), ws.numel() * 4, stream()), "nvq_bn2_stats")
+                                      ptr(ws), ws.numel() * 4, _bf(x), stream()), "nvq_bn2_stats")
         else:
             check(lib().nvq_bn2_eval_stats(ptr(rmean), ptr(rvar), C, BN_EPS, ptr(mean), ptr(invstd), stream()), "nvq_bn2_eval_stats")
         y = torch.empty_like(x)
         check(lib().nvq_bn2_apply(ptr(x), ld, C, npix, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(res),
-                                  res.shape[-1] if res is not None else 0, int(relu), ptr(y), ld, stream()), "nvq_bn2_apply")
+                                  res.shape[-1] if res is not None else 0, int(relu), ptr(y), ld, _bf(x), stream()), "nvq_bn2_apply")
         ctx.save_for_backward(x, gamma, beta, res, mean, invstd)
         ctx.training, ctx.relu = training, relu
         return y
@@ -282,16 +334,15 @@ class BatchNorm(torch.autograd.Function):
         N, H, W, ld = x.shape
         C = gamma.numel()
         dy = dy.contiguous()
+        assert dy.dtype == x.dtype
         dx = torch.empty_like(x)
         dres = torch.empty_like(res) if res is not None else None
-        if dres is not None and dres.shape[-1] > C:
-            dres[..., C:].zero_()
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         ws = _ws(x)
         check(lib().nvq_bn2_backward(ptr(dy), dy.shape[-1], ptr(x), ld, C, N * H * W, ptr(mean), ptr(invstd), ptr(gamma),
                                      ptr(beta), ptr(res), res.shape[-1] if res is not None else 0, int(ctx.relu),
                                      int(ctx.training), ptr(dx), ld, ptr(dres), dres.shape[-1] if dres is not None else 0,
-                                     ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, stream()), "nvq_bn2_backward")
+                                     ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, _bf(x), stream()), "nvq_bn2_backward")
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 
@@ -303,9 +354,9 @@ class MaxPool(torch.autograd.Function):
     def forward(ctx, x, k: int, s: int, pad: int):
         N, H, W, ld = x.shape
         OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-        y = _new(x, N, OH, OW, ld)
+        y = _new(x, N, OH, OW, ld, dtype=x.dtype)
         idx = _new(x, N, OH, OW, ld, dtype=torch.uint8)
-        check(lib().nvq_maxpool_forward(ptr(x), ld, N, H, W, k, s, pad, ptr(y), ptr(idx), stream()), "nvq_maxpool_forward")
+        check(lib().nvq_maxpool_forward(ptr(x), ld, N, H, W, k, s, pad, ptr(y), ptr(idx), _bf(x), stream()), "nvq_maxpool_forward")
         ctx.save_for_backward(idx)
         ctx.args = (N, H, W, ld, k, s, pad)
         return y
@@ -315,8 +366,8 @@ class MaxPool(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         N, H, W, ld, k, s, pad = ctx.args
         dy = dy.contiguous()
-        dx = _new(dy, N, H, W, ld)
-        check(lib().nvq_maxpool_backward(ptr(dy), ptr(idx), ld, N, H, W, k, s, pad, ptr(dx), stream()), "nvq_maxpool_backward")
+        dx = _new(dy, N, H, W, ld, dtype=dy.dtype)
+        check(lib().nvq_maxpool_backward(ptr(dy), ptr(idx), ld, N, H, W, k, s, pad, ptr(dx), _bf(dy), stream()), "nvq_maxpool_backward")
         return dx, None, None, None
 
 
@@ -326,8 +377,8 @@ class Subsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         N, H, W, ld = x.shape
-        y = _new(x, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, ld)
-        check(lib().nvq_subsample2(ptr(x), ld, N, H, W, ptr(y), 0, stream()), "nvq_subsample2")
+        y = _new(x, N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, ld, dtype=x.dtype)
+        check(lib().nvq_subsample2(ptr(x), ld, N, H, W, ptr(y), 0, _bf(x), stream()), "nvq_subsample2")
         ctx.shape = (N, H, W, ld)
         return y
 
@@ -335,8 +386,8 @@ class Subsample2(torch.autograd.Function):
     def backward(ctx, dy):
         N, H, W, ld = ctx.shape
         dy = dy.contiguous()
-        dx = _new(dy, N, H, W, ld)
-        check(lib().nvq_subsample2(ptr(dy), ld, N, H, W, ptr(dx), 1, stream()), "nvq_subsample2")
+        dx = _new(dy, N, H, W, ld, dtype=dy.dtype)
+        check(lib().nvq_subsample2(ptr(dy), ld, N, H, W, ptr(dx), 1, _bf(dy), stream()), "nvq_subsample2")
         return dx
 
 
@@ -346,6 +397,7 @@ class Resize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH: int, OW: int):
         N, H, W, ld = x.shape
+        assert x.dtype == torch.float32
         y = _new(x, N, OH, OW, ld)
         check(lib().nvq_bilinear_resize(ptr(x), ld, N, H, W, OH, OW, ptr(y), 0, stream()), "nvq_bilinear_resize")
         ctx.args = (N, H, W, ld, OH, OW)
@@ -368,15 +420,15 @@ class DepthToSpace2(torch.autograd.Function):
     def forward(ctx, u):
         N, H, W, c = u.shape
         Co = c // 4
-        y = _new(u, N, 2 * H, 2 * W, Co)
-        check(lib().nvq_depth_space2(ptr(u), ptr(y), N, H, W, Co, 0, stream()), "nvq_depth_space2")
+        y = _new(u, N, 2 * H, 2 * W, Co, dtype=u.dtype)
+        check(lib().nvq_depth_space2(ptr(u), ptr(y), N, H, W, Co, 0, _bf(u), stream()), "nvq_depth_space2")
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, H2, W2, Co = dy.shape
-        du = _new(dy, N, H2 // 2, W2 // 2, 4 * Co)
-        check(lib().nvq_depth_space2(ptr(dy.contiguous()), ptr(du), N, H2 // 2, W2 // 2, Co, 1, stream()), "nvq_depth_space2")
+        du = _new(dy, N, H2 // 2, W2 // 2, 4 * Co, dtype=dy.dtype)
+        check(lib().nvq_depth_space2(ptr(dy.contiguous()), ptr(du), N, H2 // 2, W2 // 2, Co, 1, _bf(dy), stream()), "nvq_depth_space2")
         return du
 
 
@@ -385,24 +437,25 @@ class GroupMean(torch.autograd.Function):
     frame_recovery.py:137,164-165)"""
 
     @staticmethod
-    def forward(ctx, x, T: int):
-        NB = x.shape[0]
+    def forward(ctx, x, T: int, C: int):
+        NB, H, W, ld = x.shape
         B = NB // T
-        y = torch.empty_like(x[:B])
+        y = _new(x, B, H, W, pad4(C))                        # the mean is fp32 whatever the storage type of x
         for t in range(T):
-            K.axpy_slice(Sl(y), Sl(x[t * B:(t + 1) * B]), 1.0 / T, accumulate=t > 0)
-        ctx.T = T
+            cast_slice_(y, x[t * B:(t + 1) * B], pad4(C), alpha=1.0 / T, accumulate=t > 0)
+        ctx.T, ctx.src = T, (x.dtype, ld)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         T = ctx.T
+        dtype, ld = ctx.src
         dy = dy.contiguous()
-        B = dy.shape[0]
-        dx = _new(dy, T * B, *dy.shape[1:])
+        B, H, W, c4 = dy.shape
+        dx = _new(dy, T * B, H, W, ld, dtype=dtype, zero=ld > c4)
         for t in range(T):
-            K.axpy_slice(Sl(dx[t * B:(t + 1) * B]), Sl(dy), 1.0 / T, accumulate=False)
-        return dx, None
+            cast_slice_(dx[t * B:(t + 1) * B], dy, c4, alpha=1.0 / T)
+        return dx, None, None
 
 
 class Cat2(torch.autograd.Function):

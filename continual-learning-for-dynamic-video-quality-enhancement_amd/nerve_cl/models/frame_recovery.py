@@ -13,6 +13,7 @@ three accumulating 1x1 convolutions over shifted image ranges.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -44,8 +45,8 @@ class SpatialEncoder(_Holder):
         layers += [ResidualBlock(cout) for _ in range(num_blocks)]
         return Stack(*layers)
 
-    def forward_nhwc(self, x4: torch.Tensor, math: int) -> "Tuple[torch.Tensor, List[torch.Tensor]]":
-        y = _ops.Stem7.apply(x4, self.stem[0].weight)
+    def forward_nhwc(self, x4: torch.Tensor, math: int, act_dtype=torch.float32) -> "Tuple[torch.Tensor, List[torch.Tensor]]":
+        y = _ops.Stem7.apply(x4, self.stem[0].weight, act_dtype)
         y = _ops.bn(y, self.stem[1], self.training, relu=True)
         y = _ops.MaxPool.apply(y, 3, 2, 1)
         skips = [y]
@@ -58,7 +59,8 @@ class SpatialEncoder(_Holder):
                     y = _ops.bn(y, layer[1], self.training, relu=False)
             if si < 2:
                 skips.append(y)
-        return self.attention.forward_nhwc(y), skips
+        # the attention kernels (global pooling, 7x7 conv over channel statistics) are fp32; at 1/16 resolution
+        return self.attention.forward_nhwc(_ops.Cast.apply(y, torch.float32, y.shape[-1])), skips
 
 
 class TemporalEncoder(_Holder):
@@ -72,10 +74,10 @@ class TemporalEncoder(_Holder):
         self.conv3 = TemporalConv3D(128, out_channels, temporal_kernel=3)
         self.temporal_pool = Act()
 
-    def forward_nhwc(self, frames: torch.Tensor, T: int, math: int) -> torch.Tensor:
-        y = _ops.MaxPool.apply(self.conv1.forward_nhwc(frames, T, math), 2, 2, 0)
+    def forward_nhwc(self, frames: torch.Tensor, T: int, math: int, act_dtype=torch.float32) -> torch.Tensor:
+        y = _ops.MaxPool.apply(self.conv1.forward_nhwc(frames, T, math, act_dtype), 2, 2, 0)
         y = _ops.MaxPool.apply(self.conv2.forward_nhwc(y, T, math), 2, 2, 0)
-        return _ops.GroupMean.apply(self.conv3.forward_nhwc(y, T, math), T)
+        return _ops.GroupMean.apply(self.conv3.forward_nhwc(y, T, math), T, self.conv3.out_channels)   # fp32 out
 
 
 class FusionModule(_Holder):
@@ -114,11 +116,12 @@ class Decoder(_Holder):
             setattr(self, f"up{i}", Stack(nn.ConvTranspose2d(ci, co, 4, 2, 1, bias=False), nn.BatchNorm2d(co), Act()))
         self.final = Stack(nn.Conv2d(base_channels // 2, out_channels, 3, 1, 1), Act())
 
-    def forward_nhwc(self, x: torch.Tensor, math: int) -> torch.Tensor:
+    def forward_nhwc(self, x: torch.Tensor, math: int, act_dtype=torch.float32) -> torch.Tensor:
+        x = _ops.Cast.apply(x, act_dtype, x.shape[-1])
         for i in (1, 2, 3, 4):
             up = getattr(self, f"up{i}")
             x = _ops.bn(_ops.ConvT.apply(x, up[0].weight, math), up[1], self.training, relu=True)
-        return _ops.Tanh.apply(_ops.Conv.apply(x, self.final[0].weight, self.final[0].bias, False, math))
+        return _ops.Tanh.apply(_ops.Conv.apply(x, self.final[0].weight, self.final[0].bias, False, math, torch.float32))
 
 
 class _FRFunction(torch.autograd.Function):
@@ -185,7 +188,12 @@ class FrameRecoveryNet(BucketedNet):
                                                 temporal_window=temporal_window)
         self.fusion = FusionModule(base_channels * 4, base_channels * 4, base_channels * 4)
         self.decoder = Decoder(base_channels * 4, in_channels, base_channels)
-        self.math_mode = _nvq.MATH_F32            # MATH_BF16: bf16 MFMA operands in every convolution (fp32 storage)
+        # Precision knobs (as on SuperResolutionNet): math_mode MATH_BF16 = bf16 MFMA operands in every convolution;
+        # bf16_activations (only honoured then) = the encoders' and the decoder's activations and their gradients stored as
+        # bf16 (statistics, the 1/16-resolution attention / fusion stage and the output image stay fp32)
+        bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
+        self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
+        self.bf16_activations = os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
         self._init_bucket()
 
     # ------------------------------------------------------------------ the layer graph (NHWC, libnvq ops)
@@ -193,15 +201,16 @@ class FrameRecoveryNet(BucketedNet):
         B, C, H, W = frame.shape
         T = refs.shape[1]
         math = self.math_mode
+        act = torch.bfloat16 if (math == _nvq.MATH_BF16 and self.bf16_activations) else torch.float32
         x4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=frame.device)
         _ops.nchw_to_nhwc_(frame, C * H * W, B, C, H, W, x4, 0)
         _ops.nchw_to_nhwc_(mask, H * W, B, 1, H, W, x4, C)
-        sp, _skips = self.spatial_encoder.forward_nhwc(x4, math)
+        sp, _skips = self.spatial_encoder.forward_nhwc(x4, math, act)
         r = torch.empty(T * B, H, W, 4, dtype=torch.float32, device=frame.device)
         for t in range(T):                                        # time-major image batch, channel 3 = 0
             _ops.nchw_to_nhwc_(refs, T * C * H * W, B, C, H, W, r[t * B:(t + 1) * B], 0, czero=4, src_offset=t * C * H * W)
-        tp = self.temporal_encoder.forward_nhwc(r, T, math)
-        rec = self.decoder.forward_nhwc(self.fusion.forward_nhwc(sp, tp, math), math)
+        tp = self.temporal_encoder.forward_nhwc(r, T, math, act)
+        rec = self.decoder.forward_nhwc(self.fusion.forward_nhwc(sp, tp, math), math, act)
         if rec.shape[1:3] != (H, W):
             rec = _ops.Resize.apply(rec, H, W)
         return _ops.MaskBlend.apply(frame, rec, mask)

@@ -185,10 +185,10 @@ class TemporalConv3D(_Holder):
                               nn.BatchNorm3d(out_channels), Act())
         self.math_mode = MATH_F32
 
-    def forward_nhwc(self, x: torch.Tensor, T: int, math: int = MATH_F32) -> torch.Tensor:
-        """x: time-major image batch [T*B, H, W, ld]"""
+    def forward_nhwc(self, x: torch.Tensor, T: int, math: int = MATH_F32, act_dtype=None) -> torch.Tensor:
+        """x: time-major image batch [T*B, H, W, ld]; act_dtype: storage type of the block's activations (default: x's)"""
         w = self.spatial[0].weight
-        y = _ops.Conv.apply(x, w.view(w.shape[0], w.shape[1], 3, 3), None, False, math)
+        y = _ops.Conv.apply(x, w.view(w.shape[0], w.shape[1], 3, 3), None, False, math, act_dtype)
         y = _ops.bn(y, self.spatial[1], self.training, relu=True)
         y = _ops.TemporalConv.apply(y, self.temporal[0].weight, T, math)
         return _ops.bn(y, self.temporal[1], self.training, relu=True)

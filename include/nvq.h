@@ -358,8 +358,10 @@ int nvq_mse_backward(const float* a, const float* b, long n, const float* grad_o
                      void* stream);
 
 /* ------------------------------------------------------------------ FrameRecoveryNet layers (csrc/fr_ops.hip)
- * Generic fp32 NHWC kernels for reference nerve_cl/models/frame_recovery.py:23-446 (+ efficient_layers.py:109-151,
- * 231-294).  Tensors are [N,H,W,ld] fp32, logical channel count C <= ld, ld % 4 == 0, channels [C, ld) kept 0. */
+ * Generic NHWC kernels for reference nerve_cl/models/frame_recovery.py:23-446 (+ efficient_layers.py:109-151,
+ * 231-294).  Tensors are [N,H,W,ld], logical channel count C <= ld, ld % 4 == 0, channels [C, ld) kept 0; fp32, or -
+ * where an entry point has a `bf16` flag and it is set - bf16 for every activation tensor of that call (statistics,
+ * parameters and their gradients are always fp32). */
 /* dst[n,p,dst_coff+c] = src[n*src_nstride + c*H*W + p] (c < C), 0 for C <= c < czero: NCHW image (or frame t of a
  * (B,T,C,H,W) clip: src + t*C*H*W, src_nstride = T*C*H*W) into an NHWC slice */
 int nvq_nchw_to_nhwc(const float* src, long src_nstride, int N, int C, int H, int W, float* dst,
@@ -373,28 +375,28 @@ int nvq_nhwc_to_nchw(const float* src, int src_ld, int src_coff, int N, int C, i
 size_t nvq_bn2_workspace_bytes(int C);
 int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float momentum, float* mean,
                   float* invstd, float* running_mean, float* running_var, float* workspace,
-                  size_t workspace_bytes, void* stream);
+                  size_t workspace_bytes, int bf16, void* stream);
 int nvq_bn2_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
                        float* mean, float* invstd, void* stream);
 int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, const float* res, int res_ld, int relu,
-                  float* out, int out_ld, void* stream);
+                  float* out, int out_ld, int bf16, void* stream);
 /* g = dy masked by the forward ReLU (recomputed from x, res); dgamma = sum g*xhat, dbeta = sum g; dx as BatchNorm's
  * backward (training) or gamma*invstd*g (eval); dres = g when res != NULL */
 int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C, long npix,
                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const float* res, int res_ld, int relu, int training, float* dx, int dx_ld,
                      float* dres, int dres_ld, float* dgamma, float* dbeta, float* workspace,
-                     size_t workspace_bytes, void* stream);
+                     size_t workspace_bytes, int bf16, void* stream);
 /* nn.MaxPool2d(k, s, pad) (frame_recovery.py:46) and F.max_pool3d(x, (1,2,2)) (:155,158): first maximum in scan order
  * wins (PyTorch's tie rule, matters after ReLU); idx = one byte per element; the backward is a gather (no atomics) */
 int nvq_maxpool_forward(const float* x, int ld, int N, int H, int W, int k, int s, int pad, float* out,
-                        uint8_t* idx, void* stream);
+                        uint8_t* idx, int bf16, void* stream);
 int nvq_maxpool_backward(const float* dy, const uint8_t* idx, int ld, int N, int H, int W, int k, int s,
-                         int pad, float* dx, void* stream);
+                         int pad, float* dx, int bf16, void* stream);
 /* input side of nn.Conv2d(k=1, stride=2) (frame_recovery.py:71): out[n,y,x] = in[n,2y,2x]; backward = zero insertion
  * (in = gradient at the subsampled size, out = gradient at H x W) */
-int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int backward, void* stream);
+int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int backward, int bf16, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) (frame_recovery.py:224-229,433-436); backward (gather form):
  * in = dy [N,OH,OW], out = dx [N,H,W] */
 int nvq_bilinear_resize(const float* in, int ld, int N, int H, int W, int OH, int OW, float* out,
@@ -404,7 +406,7 @@ int nvq_bilinear_resize(const float* in, int ld, int N, int H, int W, int OH, in
  * maps its gradient back, nvq_depth_space2 moves [N,H,W,4*Co] <-> [N,2H,2W,Co] */
 int nvq_convt_pack(const float* w, int Ci, int Co, float* w3, void* stream);
 int nvq_convt_unpack_grad(const float* dw3, int Ci, int Co, float* dw, void* stream);
-int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, void* stream);
+int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, int bf16, void* stream);
 /* TemporalConv3D's nn.Conv3d(Ci, Co, (3,1,1)) weight [Co,Ci,3,1,1] (efficient_layers.py:271-278) -> three 1x1 conv
  * weights [3][Co][Ci] (to_taps = 1) and back (its gradient, to_taps = 0): the temporal conv runs as three accumulating
  * 1x1 convolutions over time-shifted image ranges */
@@ -432,9 +434,13 @@ int nvq_mask_blend_backward(const float* dout, const float* mask, int N, int C, 
 /* SpatialEncoder stem nn.Conv2d(4, Co, 7, 2, 3, bias=False) (frame_recovery.py:42-44) on a 4-channel NHWC image;
  * w / dw in PyTorch layout [Co,4,7,7]; wgrad workspace >= 256*64*196 floats */
 int nvq_stem7_forward(const float* x, const float* w, int N, int H, int W, int Co, float* out, int out_ld,
-                      void* stream);
+                      int out_bf16, void* stream);
 int nvq_stem7_wgrad(const float* x, const float* dy, int dy_ld, int N, int H, int W, int Co, float* dw,
-                    float* workspace, size_t workspace_bytes, void* stream);
+                    float* workspace, size_t workspace_bytes, int dy_bf16, void* stream);
+/* dst[p, dst_coff + c] (+)= alpha * src[p, src_coff + c], c < C, each side fp32 or bf16 ([npix, ld] tensors): storage-type
+ * boundary of FrameRecoveryNet's bf16 stages, mean / broadcast over the time groups (frame_recovery.py:164-165) */
+int nvq_cast_slice(float* dst, int dst_ld, int dst_coff, int dst_bf16, const float* src, int src_ld,
+                   int src_coff, int src_bf16, int C, long npix, float alpha, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ small helpers */
 /* dst[n,p,dst_coff+c] (+)= alpha*src[n,p,src_coff+c] [* (mask[n,p,mask_coff+c] > 0)] for c < C; src may be stored as

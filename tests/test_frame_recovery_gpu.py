@@ -98,10 +98,13 @@ def test_no_mask_eval_nograd_and_default_mask():
         net(corrupted, refs, mask)                            # CPU tensors: no fallback
 
 
-def test_bf16_math_mode_quality():
+@pytest.mark.parametrize("bf16_storage", [True, False])
+def test_bf16_math_mode_quality(bf16_storage):
+    """bf16 MFMA operands, with the encoders' / decoder's activations stored as bf16 (the mode bench.py --recovery times)
+    or as fp32"""
     from nerve_cl import _nvq
     net, P = build(16, 2, True)
-    net.math_mode = _nvq.MATH_BF16
+    net.math_mode, net.bf16_activations = _nvq.MATH_BF16, bf16_storage
     corrupted, refs, mask, tgt = inputs(2, 2, 128, 160)        # 8x10 pixels x 2 images left at the bottleneck's BatchNorms
     out = net(corrupted.cuda(), refs.cuda(), mask.cuda())
     loss = F.mse_loss(out, tgt.cuda())
@@ -117,14 +120,14 @@ def test_bf16_math_mode_quality():
     ga = torch.cat([p.grad.double().cpu().reshape(-1) for _, p in net.named_parameters()])
     gb = torch.cat([P[n].grad.double().reshape(-1) for n, _ in net.named_parameters()])
     cos_all = float((ga @ gb) / (ga.norm() * gb.norm()))
-    print(f"  FR bf16 math: PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, gradient "
+    print(f"  FR bf16 math (bf16 storage {bf16_storage}): PSNR vs fp32 oracle {psnr:.1f} dB, loss {loss.item():.6f} vs {o_loss.item():.6f}, gradient "
           f"cosine {cos_all:.4f}")
     assert psnr > 40.0 and abs(loss.item() - o_loss.item()) < 2e-3 * o_loss.item() and cos_all > 0.95
     # three AdamW steps in bf16 mode next to the same three steps in the exact-fp32 mode of the same kernels
     losses = {}
     for mode in (_nvq.MATH_BF16, _nvq.MATH_F32):
         m, _ = build(16, 2, True)
-        m.math_mode = mode
+        m.math_mode, m.bf16_activations = mode, bf16_storage
         opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
         ls = []
         for _ in range(3):

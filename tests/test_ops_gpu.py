@@ -131,7 +131,7 @@ def test_subsample_resize_depth_to_space_groupmean_cat():
     run_pair(lambda i, p: _ops.DepthToSpace2.apply(i[0]),
              lambda i, p: i[0].view(2, 2, 2, 8, 5, 6).permute(0, 3, 4, 1, 5, 2).reshape(2, 8, 10, 12), [x], [], 8)
     xt = T(6, 8, 4, 5)                       # time-major [T*B] with T = 3, B = 2
-    run_pair(lambda i, p: _ops.GroupMean.apply(i[0], 3), lambda i, p: i[0].view(3, 2, 8, 4, 5).mean(0), [xt], [], 8)
+    run_pair(lambda i, p: _ops.GroupMean.apply(i[0], 3, 8), lambda i, p: i[0].view(3, 2, 8, 4, 5).mean(0), [xt], [], 8)
     run_pair(lambda i, p: _ops.Cat2.apply(i[0], i[1]), lambda i, p: torch.cat(i, dim=1), [T(2, 8, 4, 5), T(2, 12, 4, 5)], [], 20)
 
 
@@ -208,6 +208,59 @@ def test_fusion_mix_tanh_blend():
     out.backward(d.cuda())
     ref.backward(d)
     assert rel(rec_g.grad, rec.grad) < TOL
+
+
+def test_bf16_storage_variants_of_the_frame_recovery_ops():
+    """the same kernels with bf16-stored activations (FrameRecoveryNet's throughput mode): each op on a bf16 tensor against
+    the fp32 op on the same (bf16-representable) values; differences = one bf16 rounding of the result (2^-8 relative)"""
+    from nerve_cl import _nvq, _ops
+    torch.manual_seed(12)
+    B16, TOLB = torch.bfloat16, 1.2e-2
+
+    def pair(fn, x, C, *params, grad_in=True, keeps_dtype=True):
+        """fn(x_nhwc, *params) -> nhwc; returns (bf16 result, fp32 result) and checks outputs and input gradients"""
+        xq = x.bfloat16().float()
+        outs, grads = [], []
+        for dt in (B16, torch.float32):
+            xi = nhwc(xq.clone().requires_grad_(grad_in))
+            xin = _ops.Cast.apply(xi, dt, C)
+            leaf = xin.detach().requires_grad_(grad_in)
+            y = fn(leaf, *[p.detach().cuda().requires_grad_(True) for p in params])
+            assert y.dtype == (dt if keeps_dtype else torch.float32)
+            yf = _ops.Cast.apply(y, torch.float32, y.shape[-1])
+            torch.manual_seed(1)
+            d = torch.randn_like(yf).bfloat16().float()
+            if grad_in:
+                yf.backward(d)
+                grads.append(_ops.Cast.apply(leaf.grad, torch.float32, C))
+            outs.append(yf)
+        assert rel(outs[0], outs[1]) < TOLB, rel(outs[0], outs[1])
+        if grad_in:
+            assert rel(grads[0], grads[1]) < 2 * TOLB, rel(grads[0], grads[1])
+
+    C = 64
+    gamma, beta = 1 + 0.2 * torch.randn(C), 0.1 * torch.randn(C)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    pair(lambda x, g, b: _ops.BatchNorm.apply(x, g, b, None, rm.clone(), rv.clone(), True, True), torch.randn(2, C, 9, 10), C, gamma, beta)
+    pair(lambda x, g, b: _ops.BatchNorm.apply(x, g, b, x, rm.clone(), rv.clone(), True, True), torch.randn(2, C, 9, 10), C, gamma, beta)
+    g230, b230 = 1 + 0.2 * torch.randn(230), 0.1 * torch.randn(230)
+    pair(lambda x, g, b: _ops.BatchNorm.apply(x, g, b, None, torch.zeros(230).cuda(), torch.ones(230).cuda(), True, True),
+         torch.randn(2, 230, 6, 7), 230, g230, b230)
+    pair(lambda x: _ops.MaxPool.apply(x, 3, 2, 1), F.relu(torch.randn(2, C, 12, 14)), C)
+    pair(lambda x: _ops.MaxPool.apply(x, 2, 2, 0), torch.randn(2, C, 12, 14), C)
+    pair(lambda x: _ops.Subsample2.apply(x), torch.randn(2, C, 9, 12), C)
+    pair(lambda x: _ops.DepthToSpace2.apply(x), torch.randn(2, C, 5, 6), C)
+    pair(lambda x: _ops.GroupMean.apply(x, 2, C), torch.randn(4, C, 5, 6), C, keeps_dtype=False)   # the mean is fp32
+    pair(lambda x, w: _ops.DwConv.apply(x, w), torch.randn(2, C, 9, 10), C, 0.3 * torch.randn(C, 1, 3, 3))
+    pair(lambda x, w: _ops.Conv.apply(x, w, None, False, _nvq.MATH_BF16), torch.randn(2, C, 9, 10), C, torch.randn(230, C, 3, 3) / 24)
+    pair(lambda x, w: _ops.Conv.apply(x, w, None, False, _nvq.MATH_BF16), torch.randn(2, 230, 9, 10), 230, torch.randn(128, 230, 1, 1) / 15)
+    pair(lambda x, w: _ops.TemporalConv.apply(x, w, 2, _nvq.MATH_BF16), torch.randn(4, 230, 5, 6), 230, torch.randn(128, 230, 3, 1, 1) / 26)
+    pair(lambda x, w: _ops.ConvT.apply(x, w, _nvq.MATH_BF16), torch.randn(2, C, 5, 6), C, torch.randn(C, 32, 4, 4) / 16)
+    x4 = torch.randn(2, 4, 20, 24)
+    w7 = (torch.randn(16, 4, 7, 7) / 14).cuda()
+    a = _ops.Stem7.apply(nhwc(x4), w7, B16)
+    b = _ops.Stem7.apply(nhwc(x4), w7, torch.float32)
+    assert a.dtype == B16 and rel(a.float(), b) < TOLB
 
 
 def test_standalone_layer_modules_match_the_reference_layers_semantics():
