@@ -175,35 +175,41 @@ __global__ __launch_bounds__(256) void bn2_eval_stats_kernel(const float* __rest
     invstd[c] = 1.f / sqrtf(rvar[c] + eps);
 }
 
-// y = bn(x) (+ res) (ReLU); channels [C, out_ld) written as 0.  One thread per (pixel, 4 channels).
+// y = bn(x) (+ res) (ReLU); channels [C, out_ld) written as 0.  A thread owns one 4-channel group (its parameters are
+// loaded once) and walks the workgroup's pixel range, 256 / G4 pixels per step.
 __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ res, int res_ld, int relu,
                                                         float* __restrict__ out, int out_ld, int bf) {
-    const int g4 = out_ld >> 2;
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= npix * g4) return;
-    const int c = 4 * (int)(gid % g4);
-    const long p = gid / g4;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C) {
+    const int G4 = out_ld >> 2;                      // groups written per pixel (padding groups get zeros)
+    const int rows = 256 / G4;
+    const int g = threadIdx.x % G4, row = threadIdx.x / G4;
+    if (row >= rows) return;
+    const int c = 4 * g;
+    const long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    if (c >= C) {
+        for (long p = p0 + row; p < p1; p += rows) stx4(out, p * out_ld + c, bf, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
+    const float4 m = cpar(mean, c, C), is = cpar(invstd, c, C), ga = cpar(gamma, c, C), be = cpar(beta, c, C);
+    for (long p = p0 + row; p < p1; p += rows) {
         const float4 v = ldx4(x, p * x_ld + c, bf);
-        const float4 m = cpar(mean, c, C), is = cpar(invstd, c, C), ga = cpar(gamma, c, C), be = cpar(beta, c, C);
-        o = make_float4((v.x - m.x) * is.x * ga.x + be.x, (v.y - m.y) * is.y * ga.y + be.y, (v.z - m.z) * is.z * ga.z + be.z,
-                        (v.w - m.w) * is.w * ga.w + be.w);
+        float4 o = make_float4((v.x - m.x) * is.x * ga.x + be.x, (v.y - m.y) * is.y * ga.y + be.y, (v.z - m.z) * is.z * ga.z + be.z,
+                               (v.w - m.w) * is.w * ga.w + be.w);
         if (res) {
             const float4 r = ldx4(res, p * res_ld + c, bf);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        if (c + 3 >= C) {                                // last, partial group: padding channels stay 0
+        if (c + 3 >= C) {                            // last, partial group: padding channels stay 0
             if (c + 1 >= C) o.y = 0.f;
             if (c + 2 >= C) o.z = 0.f;
             o.w = 0.f;
         }
+        stx4(out, p * out_ld + c, bf, o);
     }
-    stx4(out, p * out_ld + c, bf, o);
 }
 
 __global__ __launch_bounds__(256) void bn2_bwd_final_kernel(const float* __restrict__ part, int nblk, int C,
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_final_kernel(const float* __restr
 
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))   (training)   |   gamma * invstd * g   (eval)
 // g is read from `g` when given (written by the partial pass), else recomputed from dy and the ReLU of bn(x).
+// Same thread mapping as bn2_apply_kernel.
 __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                             const float* __restrict__ dy, int dy_ld,
                                                             const float* __restrict__ g, int g_ld,
@@ -229,40 +236,39 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ sums, int relu, int training,
                                                             float* __restrict__ dx, int dx_ld, int bf) {
-    const int g4 = dx_ld >> 2;
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= npix * g4) return;
-    const int c = 4 * (int)(gid % g4);
-    const long p = gid / g4;
+    const int G4 = dx_ld >> 2;
+    const int rows = 256 / G4;
+    const int gi = threadIdx.x % G4, row = threadIdx.x / G4;
+    if (row >= rows) return;
+    const int c = 4 * gi;
+    const long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    if (c >= C) {
+        for (long p = p0 + row; p < p1; p += rows) stx4(dx, p * dx_ld + c, bf, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     const float inv_n = 1.f / (float)npix;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) {
+    const float4 m4 = cpar(mean, c, C), is4 = cpar(invstd, c, C), ga4 = cpar(gamma, c, C), be4 = cpar(beta, c, C);
+    const float4 sa = cpar(sums, c, C), sb = cpar(sums + C, c, C);
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+    const float be[4] = {be4.x, be4.y, be4.z, be4.w};
+    const float k1[4] = {sa.x * inv_n, sa.y * inv_n, sa.z * inv_n, sa.w * inv_n};
+    const float k2[4] = {sb.x * inv_n, sb.y * inv_n, sb.z * inv_n, sb.w * inv_n};
+    for (long p = p0 + row; p < p1; p += rows) {
         const float4 v = ldx4(x, p * x_ld + c, bf);
-        const float4 m = cpar(mean, c, C), is4 = cpar(invstd, c, C), ga4 = cpar(gamma, c, C);
-        const float xv[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m.x, m.y, m.z, m.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-        const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
-        float gv[4];
-        if (g) {
-            const float4 t = ldx4(g, p * g_ld + c, bf);
-            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-        } else {
-            const float4 t = ldx4(dy, p * dy_ld + c, bf);
-            gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-        }
-        const float4 be4 = cpar(beta, c, C);
-        const float be[4] = {be4.x, be4.y, be4.z, be4.w};
-        const float4 sa = cpar(sums, c, C), sb = cpar(sums + C, c, C);
-        const float s1[4] = {sa.x, sa.y, sa.z, sa.w}, s2[4] = {sb.x, sb.y, sb.z, sb.w};
+        const float4 t = g ? ldx4(g, p * g_ld + c, bf) : ldx4(dy, p * dy_ld + c, bf);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        const float gv[4] = {t.x, t.y, t.z, t.w};
+        float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (c + k >= C) continue;
             const float xh = (xv[k] - mm[k]) * is[k];
             float gg = gv[k];
             if (!g && relu && !(xh * ga[k] + be[k] > 0.f)) gg = 0.f;
-            o[k] = training ? ga[k] * is[k] * (gg - s1[k] * inv_n - xh * s2[k] * inv_n) : ga[k] * is[k] * gg;
+            o[k] = training ? ga[k] * is[k] * (gg - k1[k] - xh * k2[k]) : ga[k] * is[k] * gg;   // padding channels: ga = is = 0
         }
+        stx4(dx, p * dx_ld + c, bf, make_float4(o[0], o[1], o[2], o[3]));
     }
-    stx4(dx, p * dx_ld + c, bf, make_float4(o[0], o[1], o[2], o[3]));
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
@@ -799,6 +805,14 @@ static int bn2_nblk(long npix) {
     return nb < 1 ? 1 : nb;
 }
 
+// element-wise passes: ~8 pixel steps per thread, at most 16 workgroups per CU
+static int bn2_ew_blocks(long npix, int ld) {
+    const int rows = 256 / (ld / 4);
+    long nb = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
+    if (nb > 4096) nb = 4096;
+    return nb < 1 ? 1 : (int)nb;
+}
+
 size_t nvq_bn2_workspace_bytes(int C) { return (size_t)BN2_MAXBLK * 2 * (size_t)C * sizeof(float); }
 
 int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float momentum, float* mean, float* invstd,
@@ -828,7 +842,8 @@ int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean,
     NVQ_REQUIRE(C > 0 && ((C + 3) & ~3) <= x_ld && x_ld % 4 == 0 && C <= out_ld && out_ld % 4 == 0 && aligned16(out) && aligned16(x) &&
                     (!res || (((C + 3) & ~3) <= res_ld && res_ld % 4 == 0 && aligned16(res))),
                 "bn2_apply: C %d ld %d/%d", C, x_ld, out_ld);
-    hipLaunchKernelGGL(bn2_apply_kernel, dim3(blocks_for(npix * (out_ld / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, C, npix,
+    NVQ_REQUIRE(out_ld <= 1024, "bn2_apply: ld %d", out_ld);
+    hipLaunchKernelGGL(bn2_apply_kernel, dim3(bn2_ew_blocks(npix, out_ld)), dim3(256), 0, (hipStream_t)stream, x, x_ld, C, npix,
                        mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld, bf16);
     return check_launch("bn2_apply");
 }
@@ -853,7 +868,8 @@ int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C
     hipLaunchKernelGGL(bn2_bwd_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, sums, dgamma, dbeta);
     rc = check_launch("bn2_bwd_final");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(blocks_for(npix * (dx_ld / 4))), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld,
+    NVQ_REQUIRE(dx_ld <= 1024, "bn2_backward: ld %d", dx_ld);
+    hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(bn2_ew_blocks(npix, dx_ld)), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld,
                        dres, dres_ld, mean, invstd, gamma, beta, sums, relu, training, dx, dx_ld, bf16);
     return check_launch("bn2_bwd_apply");
 }
