@@ -162,6 +162,7 @@ class EWC:
         # flat buckets behind the dicts above (the dict entries are views into them):
         # key ('online' | task id) -> [(segment, fisher_flat, optpar_flat)]
         self._flat: Dict[object, "List[tuple]"] = {}
+        self._live: Dict[object, "List[bool]"] = {}      # per key: which segments ever received a gradient
         self._segs: "Optional[List[_Segment]]" = None
 
     # ------------------------------------------------------------------ helpers
@@ -203,6 +204,7 @@ class EWC:
             m._grad_bucket_hook = None
         self.model.eval()
         seen = 0
+        touched = [False] * len(segs)       # did any batch deliver a gradient to this segment (else its Fisher is exactly 0)
         try:
             for batch in dataloader:
                 if num_samples is not None and seen >= num_samples:
@@ -223,10 +225,11 @@ class EWC:
                     loss = -0.5 * (outputs ** 2).sum() if outputs.dim() > 1 else outputs.sum()
                 loss.backward()
                 with _nvq.device_guard(dev):
-                    for sg, flat in zip(segs, flats):
+                    for i, (sg, flat) in enumerate(zip(segs, flats)):
                         g = sg.grads()
                         if g is not None:
                             _nvq.fisher_accumulate(g, flat)
+                            touched[i] = True
                 seen += inputs.size(0)
         finally:
             for m, h in zip(nets, hooks):
@@ -242,6 +245,7 @@ class EWC:
         for flat in flats:
             flat /= max(seen, 1)
         self._last_fisher_flats = flats
+        self._last_fisher_touched = touched
         out: Dict[str, torch.Tensor] = {}
         for sg, flat in zip(segs, flats):
             out.update(sg.views(flat))
@@ -249,7 +253,7 @@ class EWC:
 
     def register_task(self, task_id: int, dataloader, num_samples: Optional[int] = None) -> None:
         fisher = self.compute_fisher(dataloader, num_samples)
-        segs, f_flats = self._segments(), self._last_fisher_flats
+        segs, f_flats, touched = self._segments(), self._last_fisher_flats, self._last_fisher_touched
         o_flats = [sg.theta().clone() for sg in segs]
         optpar: Dict[str, torch.Tensor] = {}
         for sg, o in zip(segs, o_flats):
@@ -259,6 +263,7 @@ class EWC:
             self.task_fisher[task_id] = fisher
             self.task_optpar[task_id] = optpar
             self._flat[task_id] = list(zip(segs, f_flats, o_flats))
+            self._live[task_id] = touched
         elif self.mode == "online":
             if len(self.fisher_dict) == 0:
                 self.fisher_dict = fisher
@@ -273,15 +278,22 @@ class EWC:
                 f_flats = merged
             self.optpar_dict = optpar
             self._flat["online"] = list(zip(segs, f_flats, o_flats))
+            old_live = self._live.get("online", [False] * len(segs))
+            self._live["online"] = [a or b for a, b in zip(old_live, touched)]
         self.num_tasks += 1
 
     # ------------------------------------------------------------------ penalty
     def _penalty_one(self, model: nn.Module, key) -> torch.Tensor:
         total = None
         if model is self.model:
-            for sg, f_flat, o_flat in self._flat[key]:
+            live = self._live.get(key)
+            for i, (sg, f_flat, o_flat) in enumerate(self._flat[key]):
+                if live is not None and not live[i]:
+                    continue                 # a segment no batch ever reached (e.g. an unused head): Fisher 0, term 0
                 term = _PenaltyFn.apply(sg, self.ewc_lambda, o_flat, f_flat, *[p for _, p in sg.named])
                 total = term if total is None else total + term
+            if total is None:
+                total = torch.zeros((), dtype=torch.float32, device=self._device())
             return total
         # another module with the same parameter names (reference signature penalty(model)): plain concatenation
         have = dict(model.named_parameters())
@@ -354,7 +366,7 @@ class EWC:
         self.num_tasks = state["num_tasks"]
         self.fisher_dict, self.optpar_dict = state["fisher_dict"], state["optpar_dict"]
         self.task_fisher, self.task_optpar = state["task_fisher"], state["task_optpar"]
-        self._flat = {}
+        self._flat, self._live = {}, {}
 
 
 class OnlineEWC(EWC):
