@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int n = pix / HW;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
+    const int n = (int)idiv(pix, HW, total);
     float4 dw = ld4(dweighted + pix * dweighted_ld + 4 * c4);
     if (dgap_pix) {
         const float4 gp = ld4(dgap_pix + (size_t)n * C + 4 * c4);
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void cbam_pool_kernel(const float* __restrict_
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int n = pix / HW;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
+    const int n = (int)idiv(pix, HW, total);
     const float4 v = ld4(x + pix * x_ld + 4 * c4);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float e[4] = {v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w};
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int n = pix / HW;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
+    const int n = (int)idiv(pix, HW, total);
     const float4 v = ld4(x + pix * x_ld + 4 * c4);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float s = sa[pix];
@@ -247,9 +247,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_pre_kernel(const float* __restri
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int n = pix / HW;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
+    const int n = (int)idiv(pix, HW, total);
     const float4 g = ld4(dout + pix * dout_ld + dout_coff + 4 * c4);
     const float4 v = ld4(x + pix * x_ld + 4 * c4);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);

@@ -53,6 +53,16 @@ __device__ __forceinline__ void stx4(float* base, size_t idx, int is_bf16, float
         st4(base + idx, v);
 }
 
+// Index decomposition without 64-bit divisions.  A 64-bit '/' or '%' by a runtime value is a ~150-instruction software
+// routine on gfx9; a launch of fewer than 2^32 work items (`total`, uniform) splits its linear id with 32-bit unsigned
+// arithmetic instead.  idiv(a, d, total) = a / d for 0 <= a < total.
+__device__ __forceinline__ long idiv(long a, int d, long total) {
+    return total <= 0xffffffffL ? (long)((unsigned)a / (unsigned)d) : a / d;
+}
+__device__ __forceinline__ long idiv(long a, long d, long total) {
+    return (total <= 0xffffffffL && d <= 0xffffffffL) ? (long)((unsigned)a / (unsigned)d) : a / d;
+}
+
 // Sum over the lanes of a wave that share the same (lane / width) group, width = power of two <= 64.
 __device__ __forceinline__ float group_sum(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -280,12 +280,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
-    const int ox = (int)(q % OW);
-    q /= OW;
-    const int oy = (int)(q % OH);
-    const int n = (int)(q / OH);
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
+    long q2 = idiv(q, OW, total);
+    const int ox = (int)(q - q2 * OW);
+    const int n = (int)idiv(q2, OH, total);
+    const int oy = (int)(q2 - (long)n * OH);
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bi[4] = {0, 0, 0, 0};
     bool first = true;
@@ -315,12 +315,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
-    const int ix = (int)(q % W);
-    q /= W;
-    const int iy = (int)(q % H);
-    const int n = (int)(q / H);
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
+    long q2 = idiv(q, W, total);
+    const int ix = (int)(q - q2 * W);
+    const int n = (int)idiv(q2, H, total);
+    const int iy = (int)(q2 - (long)n * H);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     int oy0 = (iy + pad - k + 1 + s - 1) / s, oy1 = (iy + pad) / s;      // ceil / floor
     if (iy + pad - k + 1 < 0) oy0 = 0;
@@ -349,20 +349,20 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
     if (!backward) {
-        const int ox = (int)(q % OW);
-        q /= OW;
-        const int oy = (int)(q % OH);
-        const int n = (int)(q / OH);
+        const long q2 = idiv(q, OW, total);
+        const int ox = (int)(q - q2 * OW);
+        const int n = (int)idiv(q2, OH, total);
+        const int oy = (int)(q2 - (long)n * OH);
         stx4(out, ((size_t)(n * OH + oy) * OW + ox) * ld + 4 * c4, bf,
              ldx4(in, ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ld + 4 * c4, bf));
     } else {            // `in` = gradient at [OH, OW], `out` = gradient at [H, W]
-        const int ix = (int)(q % W);
-        q /= W;
-        const int iy = (int)(q % H);
-        const int n = (int)(q / H);
+        const long q2 = idiv(q, W, total);
+        const int ix = (int)(q - q2 * W);
+        const int n = (int)idiv(q2, H, total);
+        const int iy = (int)(q2 - (long)n * H);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(iy & 1) && !(ix & 1)) v = ldx4(in, ((size_t)(n * OH + (iy >> 1)) * OW + (ix >> 1)) * ld + 4 * c4, bf);
         stx4(out, ((size_t)(n * H + iy) * W + ix) * ld + 4 * c4, bf, v);
@@ -387,12 +387,12 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
-    const int ox = (int)(q % OW);
-    q /= OW;
-    const int oy = (int)(q % OH);
-    const int n = (int)(q / OH);
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
+    long q2 = idiv(q, OW, total);
+    const int ox = (int)(q - q2 * OW);
+    const int n = (int)idiv(q2, OH, total);
+    const int oy = (int)(q2 - (long)n * OH);
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     bil_taps(oy, sy, H, y0, y1, ly0, ly1);
@@ -414,12 +414,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
-    const int ix = (int)(q % W);
-    q /= W;
-    const int iy = (int)(q % H);
-    const int n = (int)(q / H);
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
+    long q2 = idiv(q, W, total);
+    const int ix = (int)(q - q2 * W);
+    const int n = (int)idiv(q2, H, total);
+    const int iy = (int)(q2 - (long)n * H);
     int oy0 = (int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1, oy1 = (int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1;
     int ox0 = (int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1, ox1 = (int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1;
     if (oy0 < 0) oy0 = 0;
@@ -453,12 +453,12 @@ __global__ __launch_bounds__(256) void depth_space2_kernel(const float* __restri
     const int g4 = Co >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;                       // total = N * 2H * 2W * g4
-    const int c4 = (int)(gid % g4);
-    long q = gid / g4;
-    const int X = (int)(q % (2 * W));
-    q /= 2 * W;
-    const int Y = (int)(q % (2 * H));
-    const int n = (int)(q / (2 * H));
+    long q = idiv(gid, g4, total);
+    const int c4 = (int)(gid - q * g4);
+    const long q2 = idiv(q, 2 * W, total);
+    const int X = (int)(q - q2 * (2 * W));
+    const int n = (int)idiv(q2, 2 * H, total);
+    const int Y = (int)(q2 - (long)n * (2 * H));
     const size_t deep = ((size_t)(n * H + (Y >> 1)) * W + (X >> 1)) * (4 * Co) + (size_t)(((Y & 1) * 2 + (X & 1)) * Co) + 4 * c4;
     const size_t wide = ((size_t)(n * 2 * H + Y) * (2 * W) + X) * Co + 4 * c4;
     if (to_depth) stx4(out, deep, bf, ldx4(in, wide, bf));
@@ -533,9 +533,9 @@ __global__ __launch_bounds__(256) void add_image_channel_kernel(float* __restric
     const int g4 = C >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c4 = (int)(gid % g4);
-    const long p = gid / g4;
-    const int n = (int)(p / HW);
+    const long p = idiv(gid, g4, total);
+    const int c4 = (int)(gid - p * g4);
+    const int n = (int)idiv(p, HW, total);
     float4 a = ld4(x + p * ld + 4 * c4);
     const float4 b = ld4(v + (size_t)n * C + 4 * c4);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256) void cast_slice_kernel(float* __restrict__ dst
     const int g4 = C >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int c = 4 * (int)(gid % g4);
-    const long p = gid / g4;
+    const long p = idiv(gid, g4, total);
+    const int c = 4 * (int)(gid - p * g4);
     float4 v = ldx4(src, p * src_ld + src_coff + c, src_bf);
     v = make_float4(alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w);
     if (accumulate) {

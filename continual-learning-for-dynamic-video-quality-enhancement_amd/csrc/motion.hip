@@ -247,10 +247,11 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
-    const int x = pix % W;
-    const int y = (pix / W) % H;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
+    const long rowi = idiv(pix, W, total);
+    const int x = (int)(pix - rowi * W);
+    const int y = (int)(rowi - idiv(rowi, H, total) * H);
     const long img = pix - ((long)y * W + x);  // first pixel of this image
     const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -277,10 +278,11 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int L = C < 64 ? C : 64;
-    const int ch0 = gid % L;
-    const long pix = gid / L;
-    const int x = pix % W;
-    const int y = (pix / W) % H;
+    const long pix = idiv(gid, L, total);
+    const int ch0 = (int)(gid - pix * L);
+    const long rowi = idiv(pix, W, total);
+    const int x = (int)(pix - rowi * W);
+    const int y = (int)(rowi - idiv(rowi, H, total) * H);
     const long img = pix - ((long)y * W + x);
     const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
     const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
@@ -342,8 +344,9 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
     const long pix = gid >> 4;
     if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
     const int c4 = gid & 15;
-    const int x = pix % W;
-    const int y = (pix / W) % H;
+    const long rowi = idiv(pix, W, npix);
+    const int x = (int)(pix - rowi * W);
+    const int y = (int)(rowi - idiv(rowi, H, npix) * H);
     const long img = pix - ((long)y * W + x);
     const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
     const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);

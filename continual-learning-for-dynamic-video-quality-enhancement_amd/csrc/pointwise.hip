@@ -327,10 +327,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ i
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pixlin = gid / C4;
-    const int x = pixlin % W;
-    const int y = (pixlin / W) % H;
+    const long pixlin = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pixlin * C4);
+    const long rowi = idiv(pixlin, W, total);
+    const int x = (int)(pixlin - rowi * W);
+    const int y = (int)(rowi - idiv(rowi, H, total) * H);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -362,8 +363,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long p = (long)blockIdx.x * npl + pl; p < npix; p += (long)gridDim.x * npl) {
-        const int xx0 = p % W;
-        const int yy0 = (p / W) % H;
+        const long rowi = idiv(p, W, npix);
+        const int xx0 = (int)(p - rowi * W);
+        const int yy0 = (int)(rowi - idiv(rowi, H, npix) * H);
         const float4 g = ldx4(dy, (size_t)p * dy_ld + 4 * c4, dy_bf16);
 #pragma unroll
         for (int ddy = 0; ddy < 3; ++ddy) {
@@ -1051,8 +1053,8 @@ __global__ __launch_bounds__(256) void axpy_slice_kernel(float* __restrict__ dst
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
-    const int c4 = gid % C4;
-    const long pix = gid / C4;
+    const long pix = idiv(gid, C4, total);
+    const int c4 = (int)(gid - pix * C4);
     float4 v = ldx4(src, (size_t)pix * src_ld + src_coff + 4 * c4, src_bf16);
     v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
     if (mask) {

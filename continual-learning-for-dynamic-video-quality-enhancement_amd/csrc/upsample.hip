@@ -29,9 +29,10 @@ __global__ __launch_bounds__(256) void shuffle_bicubic_clamp_kernel(const float*
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int OW = W * s, OH = H * s;
-    const int ox = gid % OW;
-    const int oy = (gid / OW) % OH;
-    const int b = gid / ((long)OW * OH);
+    const long orow = idiv(gid, OW, total);
+    const int ox = (int)(gid - orow * OW);
+    const int b = (int)idiv(orow, OH, total);
+    const int oy = (int)(orow - (long)b * OH);
     const int h = oy / s, i = oy - h * s, w = ox / s, j = ox - w * s;
     int xi[4], yi[4];
     float wx[4], wy[4];
@@ -62,9 +63,10 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(float* __restrict__ 
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int OW = W * s, OH = H * s;
-    const int ox = gid % OW;
-    const int oy = (gid / OW) % OH;
-    const int b = gid / ((long)OW * OH);
+    const long orow = idiv(gid, OW, total);
+    const int ox = (int)(gid - orow * OW);
+    const int b = (int)idiv(orow, OH, total);
+    const int oy = (int)(orow - (long)b * OH);
     const int h = oy / s, i = oy - h * s, w = ox / s, j = ox - w * s;
     float* up = u + ((size_t)(b * H + h) * W + w) * u_ld;
     for (int c = 0; c < C; ++c) {
@@ -83,9 +85,10 @@ __global__ __launch_bounds__(256) void shuffle_clamp_bwd_kernel(const float* __r
                                                                  long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
-    const int w = gid % W;
-    const int h = (gid / W) % H;
-    const int b = gid / ((long)W * H);
+    const long lrow = idiv(gid, W, total);
+    const int w = (int)(gid - lrow * W);
+    const int b = (int)idiv(lrow, H, total);
+    const int h = (int)(lrow - (long)b * H);
     const int OW = W * s, OH = H * s;
     float* dp = du + (size_t)gid * du_ld;
     const int K = Cimg * s * s;
@@ -105,9 +108,10 @@ __global__ __launch_bounds__(256) void bicubic_blend_kernel(const float* __restr
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int OW = W * s, OH = H * s;
-    const int ox = gid % OW;
-    const int oy = (gid / OW) % OH;
-    const int b = gid / ((long)OW * OH);
+    const long orow = idiv(gid, OW, total);
+    const int ox = (int)(gid - orow * OW);
+    const int b = (int)idiv(orow, OH, total);
+    const int oy = (int)(orow - (long)b * OH);
     int xi[4], yi[4];
     float wx[4], wy[4];
     cubic_taps(ox, scale, W, xi, wx);

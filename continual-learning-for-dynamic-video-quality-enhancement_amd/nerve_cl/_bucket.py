@@ -16,12 +16,18 @@ re-homes every ``param.data`` as a view of one persistent buffer (checked by add
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from nerve_cl import _nvq
+
+
+class _Token:
+    """lives exactly as long as the autograd node of one forward does"""
+    __slots__ = ("__weakref__",)
 
 
 class BucketedNet(nn.Module):
@@ -33,7 +39,7 @@ class BucketedNet(nn.Module):
         self._last_grad_bucket: Optional[torch.Tensor] = None
         self._theta_flat: Optional[torch.Tensor] = None
         self._layout: Optional[Tuple[Dict[str, Tuple[int, int]], int]] = None
-        self._awaiting_backward = False        # a forward with grad has run and its backward has not yet
+        self._pending = None                   # weakref to the token of the latest forward-with-grad (see _mark_awaiting)
         self._deferred_adds: list = []         # (lam, star_flat, fisher_flat, scale_dev) to add into the next bucket
 
     # ------------------------------------------------------------------ layout
@@ -88,6 +94,19 @@ class BucketedNet(nn.Module):
             self._theta_flat = flat
         return flat
 
+    # ------------------------------------------------------------------ "is my backward still to come?"
+    def _mark_awaiting(self, ctx) -> None:
+        """Called by the network's autograd Function in forward when gradients are needed.  The token hangs on the node's
+        ctx: if the graph is dropped without a backward (a validation forward outside no_grad), the token dies with it and
+        the network stops 'awaiting' - a penalty gradient is then never parked for a backward that will not happen."""
+        ctx._nvq_token = _Token()
+        self._pending = weakref.ref(ctx._nvq_token)
+        self._deferred_adds = []               # leftovers could only come from a pass that was abandoned half-way
+
+    @property
+    def _awaiting_backward(self) -> bool:
+        return self._pending is not None and self._pending() is not None
+
     # ------------------------------------------------------------------ backward epilogue
     def _finish_bucket(self, flat: torch.Tensor) -> None:
         """Called by the network's backward once every gradient is in `flat`: data-parallel all-reduce, then the
@@ -100,5 +119,5 @@ class BucketedNet(nn.Module):
             for lam, star, fisher, scale in self._deferred_adds:
                 _nvq.ewc_penalty_grad(theta, star, fisher, lam, scale, flat, True)
             self._deferred_adds = []
-        self._awaiting_backward = False
+        self._pending = None
         self._last_grad_bucket = flat

@@ -33,7 +33,10 @@ DEBUG_CAPTURE: Optional[dict] = None
 
 
 def _capture(name: str, t) -> None:
+    """t: a tensor, or a callable producing one (evaluated only while a capture is requested)"""
     if DEBUG_CAPTURE is not None:
+        if callable(t):
+            t = t()
         DEBUG_CAPTURE[name] = t.clone() if torch.is_tensor(t) else t
 
 
@@ -306,7 +309,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     gout = dcats[(nb - 1) & 1].x() if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
     _capture("dfused", dfeat_c)
-    _capture("dres", gout.t[..., :F].float())
+    _capture("dres", lambda: gout.t[..., :F].float())
 
     # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
     K.TIMER_TAG = "rdb"
@@ -343,7 +346,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.TIMER_TAG = ""
     dprev = Sl(dagg)
 
-    _capture("dagg", dprev.t[..., dprev.coff:dprev.coff + F].float())
+    _capture("dagg", lambda: dprev.t[..., dprev.coff:dprev.coff + F].float())
     # ---- CBAM
     w1 = P["temporal_aggregator.refine.channel_attention.fc.0.weight"]
     w2 = P["temporal_aggregator.refine.channel_attention.fc.2.weight"]

@@ -142,7 +142,7 @@ class _FRFunction(torch.autograd.Function):
             out = net._graph(frame, refs, mask)
             leaves = list(params)
         ctx.inner = (out, leaves)
-        net._awaiting_backward = True
+        net._mark_awaiting(ctx)
         return out.detach()
 
     @staticmethod

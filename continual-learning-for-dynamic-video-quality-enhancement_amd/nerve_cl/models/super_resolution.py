@@ -86,7 +86,7 @@ class _SRFunction(torch.autograd.Function):
         ctx.net = net
         ctx.graph = ctx.token = None
         if need_grad:
-            net._awaiting_backward = True
+            net._mark_awaiting(ctx)
         if net._graphs_wanted(frames) and not want_inter:
             hit = net._step_graphs.forward(net, frames, need_grad, act)
             if hit is not None:
@@ -252,7 +252,7 @@ class _LightFunction(torch.autograd.Function):
         ctx.net = net
         ctx.sv = sv if any(ctx.needs_input_grad[2:]) else None
         if ctx.sv is not None:
-            net._awaiting_backward = True
+            net._mark_awaiting(ctx)
         return out
 
     @staticmethod

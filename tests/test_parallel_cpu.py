@@ -158,7 +158,7 @@ def _toy_net():
         @staticmethod
         def forward(ctx, net, x, w, b):
             ctx.net, ctx.x = net, x
-            net._awaiting_backward = True
+            net._mark_awaiting(ctx)
             return x @ w.t() + b
 
         @staticmethod
