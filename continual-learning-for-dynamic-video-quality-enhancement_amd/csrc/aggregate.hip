@@ -363,13 +363,24 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(const float* __re
     float a1[16], a2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
+    __shared__ double sp[256];
+    const int parts = 256 / C;                       // threads per channel for the partial sums (fixed order => deterministic)
     for (int n = 0; n < N; ++n) {
+        __syncthreads();
+        {
+            const int cc = c % C, part = c / C;
+            double s = 0.0;
+            if (part < parts) {
+                const float* p = dca_partial + (size_t)n * nblk * C + cc;
+                for (int b = part; b < nblk; b += parts) s += (double)p[(size_t)b * C];
+            }
+            sp[c] = s;
+        }
         __syncthreads();
         float z = 0.f;
         if (c < C) {
             double s = 0.0;
-            const float* p = dca_partial + (size_t)n * nblk * C + c;
-            for (int b = 0; b < nblk; ++b) s += (double)p[(size_t)b * C];
+            for (int k = 0; k < parts; ++k) s += sp[k * C + c];
             const float cav = ca[(size_t)n * C + c];
             z = (float)s * cav * (1.f - cav);
         }

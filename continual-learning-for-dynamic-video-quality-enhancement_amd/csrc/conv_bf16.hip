@@ -672,6 +672,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
             }
         }
     };
+    // a wave whose 16 input channels lie beyond the tensor's (the second half of a 64-channel chunk when cin % 64 == 32) has
+    // nothing to accumulate: it keeps staging with the others but leaves the matrix cores to the workgroup sharing the CU
+    const bool idle = cic * CIC + cib * 16 >= d.cin_w;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
     auto tr_read = [&](const __bf16* base, int stride, int pix, int chblock) -> s16x4 {
         // lane (q, p) supplies row `pix + q`'s address, columns 4p..4p+3 of the 16-channel block
@@ -685,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const nvq_wgrad_desc
         commit();
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if (idle) continue;                                   // (wave-uniform; the wave still staged and met the barriers)
 #pragma unroll 2
         for (int py = 0; py < TH; ++py) {
             bf16x8 bfrag[NCO];

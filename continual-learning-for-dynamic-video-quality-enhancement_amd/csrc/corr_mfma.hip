@@ -197,7 +197,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
                                                             const float* __restrict__ other, int other_ld,
                                                             int other_images, int H, int W, int tilesX, int tilesY,
                                                             float* __restrict__ dx, int dx_ld, int dx_coff,
-                                                            int accumulate, int other_bf16) {
+                                                            int accumulate, int other_bf16, int groups, int group_images) {
     constexpr int YS = WHICH == 1 ? C + 8 : C + 16;
     constexpr int NCB = C / 16;
     constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
@@ -206,9 +206,18 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
-    const int n = bt / tilesY;
+    const int n0 = bt / tilesY;
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int p = lane & 15, g = lane >> 4;
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // groups > 1 (WHICH == 2): dx of image n0 collects from the images n0 + k * group_images of dcorr / other (the T - 1
+    // reference frames of a clip) in one pass: one read-modify-write of dx instead of one per frame, fixed order
+#pragma unroll 1
+    for (int gi = 0; gi < groups; ++gi) {
+    const int n = n0 + gi * group_images;
+    if (gi > 0) __syncthreads();                             // everyone is done reading the previous group's tiles
 
     // ---- stage dcorr (channels 0..95 of each pixel; 12 pieces of 8)
     {
@@ -236,9 +245,6 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
     m_stage_halo<C, YS>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys, other_bf16);
     __syncthreads();
 
-    f32x4 acc[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     typedef m_s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
     const int trq = p >> 2, trp = p & 3;                     // tr-read role inside the 16-lane group
     const int gq = g < 3 ? g : 2;                            // halo columns 24..31 do not exist; their B rows are zero
@@ -275,11 +281,12 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfrag, acc[cb], 0, 0, 0);
         }
     }
+    }   // groups
     // D[m = channel cb*16 + 4g + e][n = pixel p]
     const int gy = ty * MT_H + r, gx = tx * MT_W + p;
     if (gy >= H || gx >= W) return;
     const float inv = 1.f / (float)C;
-    float* op = dx + ((size_t)(n * H + gy) * W + gx) * dx_ld + dx_coff + 4 * g;
+    float* op = dx + ((size_t)(n0 * H + gy) * W + gx) * dx_ld + dx_coff + 4 * g;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
@@ -310,14 +317,14 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
 
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       int other_bf16, hipStream_t s) {
+                       int other_bf16, int groups, hipStream_t s) {
     NVQ_REQUIRE(!other_bf16 || other_ld % 8 == 0, "correlation_backward(bf16): a bf16 `other` needs ld %% 8 == 0");
     NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
                 "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \
-    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16)
+    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N)
 #define NVQ_CB2(CC) \
     do { if (which == 1) { if (dcorr_bf16) NVQ_CB(CC, 1, true); else NVQ_CB(CC, 1, false); } \
          else { if (dcorr_bf16) NVQ_CB(CC, 2, true); else NVQ_CB(CC, 2, false); } } while (0)

@@ -481,7 +481,7 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
                       float* out, int out_ld, int out_bf16, int in_bf16, hipStream_t s);
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       int other_bf16, hipStream_t s);
+                       int other_bf16, int groups, hipStream_t s);
 
 }  // namespace nvq
 
@@ -508,15 +508,17 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
 
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const float* other, int other_ld,
                              int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff,
-                             int accumulate, int math, int dcorr_bf16, int other_bf16, void* stream) {
+                             int accumulate, int math, int dcorr_bf16, int other_bf16, int groups, void* stream) {
     NVQ_REQUIRE(which == 1 || which == 2, "correlation_backward: which %d", which);
+    NVQ_REQUIRE(groups >= 1 && (groups == 1 || which == 2), "correlation_backward: groups %d (only which == 2 merges frames)", groups);
+    NVQ_REQUIRE(groups == 1 || other_images >= N * groups, "correlation_backward: %d groups need %d images of `other`", groups, N * groups);
     NVQ_REQUIRE(C % 4 == 0 && dcorr_ld % 4 == 0 && dcorr_ld >= 84 && other_ld % 4 == 0 && dx_ld % 4 == 0 &&
                     dx_coff % 4 == 0 && aligned16(dcorr) && aligned16(other) && aligned16(dx),
                 "correlation_backward: alignment");
     NVQ_REQUIRE(other_images > 0, "correlation_backward: other_images");
     if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
         return corr_backward_mfma(which, dcorr, dcorr_ld, dcorr_bf16, other, other_ld, other_images, C, N, H, W, dx, dx_ld,
-                                  dx_coff, accumulate, other_bf16, (hipStream_t)stream);
+                                  dx_coff, accumulate, other_bf16, groups, (hipStream_t)stream);
     NVQ_REQUIRE(!dcorr_bf16 && !other_bf16, "correlation_backward: bf16 tensors need NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
@@ -524,8 +526,12 @@ int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const 
         hipLaunchKernelGGL((corr_bwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, dcorr, dcorr_ld, other, other_ld,
                            other_images, C, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate);
     else
-        hipLaunchKernelGGL((corr_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, dcorr, dcorr_ld, other, other_ld,
-                           other_images, C, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate);
+        for (int gi = 0; gi < groups; ++gi) {              // exact-fp32 path: one accumulating launch per reference frame
+            const size_t img = (size_t)gi * N * H * W;
+            hipLaunchKernelGGL((corr_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, dcorr + img * dcorr_ld, dcorr_ld,
+                               other + img * other_ld, other_ld, N, C, H, W, tilesX, tilesY, dx, dx_ld, dx_coff,
+                               gi > 0 ? 1 : accumulate);
+        }
     return check_launch("correlation_backward");
 }
 

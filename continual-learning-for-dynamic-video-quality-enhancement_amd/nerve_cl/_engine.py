@@ -419,9 +419,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         _capture("dcorr", dcorr)
         center = Sl(sv.aligned, F, c * F)
         K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math)
-        for j in range(1, T):
-            lo, hi = (j - 1) * B, j * B
-            K.correlation_backward(2, dcorr[lo:hi], Sl(sv.feat_oth).images(lo, hi), Sl(dfeat_c), True, math=math)
+        # gradient w.r.t. the centre frame's features: the T - 1 reference frames in one pass (one read-modify-write)
+        K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), True, math=math, groups=T - 1)
 
     # ---- feature extractor (all frames batched)
     _capture("dfeat_all", dfeat_all)

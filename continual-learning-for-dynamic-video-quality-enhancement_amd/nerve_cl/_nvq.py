@@ -92,7 +92,7 @@ SIGNATURES = {
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
@@ -624,11 +624,15 @@ def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor, math: int = MATH_F32)
                                         out.shape[-1], math, is_bf16(out), x1.bf16, stream()), "nvq_correlation_forward")
 
 
-def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32):
+def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32,
+                         groups: int = 1):
+    """groups > 1 (which == 2): dcorr / other hold groups * N images, frame-major; dx (N images) collects all of them in
+    one pass"""
     N, H, W, ld = dcorr.shape
-    check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N, H, W,
+    assert N % groups == 0
+    check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N // groups, H, W,
                                          ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), other.bf16,
-                                         stream()),
+                                         groups, stream()),
           "nvq_correlation_backward")
 
 

@@ -247,14 +247,15 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
 /* which == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d] * other[n % other_images, p+off(d), c]
  *             (gradient w.r.t. x1; other = x2)
  * which == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q-off(d),d] * other[n, q-off(d), c]
- *             (gradient w.r.t. x2 contributed by image n; other = x1, other_images = N;
- *              the caller launches once per reference frame so that the sums into the
- *              shared centre-frame gradient are ordered)
+ *             (gradient w.r.t. x2 contributed by image n; other = x1, other_images = N).
+ *             groups > 1: dcorr and other hold groups * N images (frame-major: the T - 1 reference frames of every clip);
+ *             dx[n] collects from images n, n + N, ... in that order in ONE pass (one read-modify-write of the shared
+ *             centre-frame gradient instead of one per frame)
  * math / dcorr_bf16 / other_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96).  dx is fp32. */
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
                              const float* other, int other_ld, int other_images, int C, int N,
                              int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                             int math, int dcorr_bf16, int other_bf16, void* stream);
+                             int math, int dcorr_bf16, int other_bf16, int groups, void* stream);
 
 /* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
  * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2] fp32.

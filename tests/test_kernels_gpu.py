@@ -312,6 +312,10 @@ def test_correlation_forward_backward(K, C, B, R, H, W):
     for r in range(R):
         K.correlation_backward(2, dcorr[r * B:(r + 1) * B], K.Sl(x1b).images(r * B, (r + 1) * B), K.Sl(dx2), True)
     assert rel(from_nhwc(dx2), x2.grad) < TOL
+    # the R reference frames in one call (groups): same sums, one pass over the centre-frame gradient
+    dx2m = torch.full((B, H, W, C), 2.0, device="cuda")
+    K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(dx2m), True, groups=R)
+    assert rel(from_nhwc(dx2m) - 2.0, x2.grad) < TOL
 
 
 @pytest.mark.parametrize("gather", [True, False])
@@ -696,6 +700,10 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
         K.correlation_backward(2, dcorr[r * B:(r + 1) * B], K.Sl(x1b).images(r * B, (r + 1) * B), K.Sl(dx2), True,
                                math=K.MATH_BF16)
     assert rel(from_nhwc(dx2), x2.grad) < TOL
+    dx2m = torch.zeros(B, H, W, C, device="cuda")
+    K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(dx2m), False, math=K.MATH_BF16, groups=R)
+    assert rel(from_nhwc(dx2m), x2.grad) < TOL
+    assert rel(dx2m, dx2) < 1e-6                              # same products, same order per pixel
 
 
 @pytest.mark.parametrize("Fc,N,H,W", [(64, 2, 19, 37), (64, 1, 16, 32), (32, 2, 9, 20)])
