@@ -215,3 +215,49 @@ def test_frame_recovery_bucket_feeds_ewc_and_the_fused_penalty():
     data = torch.cat([p.grad.reshape(-1) for p in net2.parameters()])
     want = data + 100.0 * fisher * 0.01
     assert rel(got, want) < 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_cfg4_geometry_full_size_against_the_oracle_and_batch_independence():
+    """BASELINE cfg4's recovery head at its real size: base 64, 4 reference frames, 270x480 (not a multiple of 16: the decoder's
+    272x480 output goes through the bilinear resize, the temporal features 67x120 -> 17x30).  One clip, fp32 math: output and
+    loss against the CPU oracle at 1e-3.  Gradients: at this size the fp32 CPU path itself is only good to ~1e-2 on the
+    tensors whose gradient is a small remainder of a sum over 130 000 pixels that BatchNorm makes cancel (oracle in fp32 vs
+    the same oracle in fp64: up to 1.1e-2), so each gradient is judged against the fp64 oracle with the fp32 oracle's own
+    error as the yardstick.  Then batch independence and determinism in eval mode."""
+    torch.manual_seed(0)
+    net, P = build(64, 4, True)
+    B, T, H, W = 1, 4, 270, 480
+    corrupted, refs, mask, tgt = inputs(B, T, H, W)
+    out = net(corrupted.cuda(), refs.cuda(), mask.cuda())
+    loss = F.mse_loss(out, tgt.cuda())
+    loss.backward()
+    o_out = fr_oracle.frame_recovery_forward(P, corrupted, refs, mask, True)
+    o_loss = F.mse_loss(o_out, tgt)
+    o_loss.backward()
+    assert rel(out, o_out) < REL and abs(loss.item() - o_loss.item()) < REL * o_loss.item()
+    sd = synth.formula_state_fr(3, 64, gain=synth.GOLDEN_GAIN)
+    P64 = {k: (v.double() if v.is_floating_point() else v.clone()).clone().requires_grad_(v.is_floating_point() and "running" not in k)
+           for k, v in sd.items()}
+    F.mse_loss(fr_oracle.frame_recovery_forward(P64, corrupted.double(), refs.double(), mask.double(), True), tgt.double()).backward()
+    worst_cpu = max(rel(P[n].grad, P64[n].grad) for n, _ in net.named_parameters())
+    worst_gpu, num, den, num_c = 0.0, 0.0, 0.0, 0.0
+    for n, p in net.named_parameters():
+        ref = P64[n].grad
+        e_gpu = rel(p.grad, ref)
+        worst_gpu = max(worst_gpu, e_gpu)
+        assert e_gpu <= max(2e-3, 3.0 * worst_cpu), (n, e_gpu, worst_cpu)     # no tensor far outside the fp32 CPU path's own band
+        num += float((p.grad.double().cpu() - ref).pow(2).sum())
+        num_c += float((P[n].grad.double() - ref).pow(2).sum())
+        den += float(ref.pow(2).sum())
+    l2, l2_cpu = (num / den) ** 0.5, (num_c / den) ** 0.5
+    print(f"  FR 270x480 base 64: out err {rel(out, o_out):.2e}; gradients vs the fp64 oracle: worst tensor {worst_gpu:.2e} "
+          f"(fp32 CPU oracle: {worst_cpu:.2e}), whole-gradient L2 {l2:.2e} (fp32 CPU oracle: {l2_cpu:.2e})")
+    assert l2 < max(2e-3, 3.0 * l2_cpu)
+    net.eval()
+    c2, r2, m2, _ = inputs(2, T, H, W)
+    with torch.no_grad():
+        both = net(c2.cuda(), r2.cuda(), m2.cuda())
+        one = net(c2[1:].cuda(), r2[1:].cuda(), m2[1:].cuda())
+        again = net(c2.cuda(), r2.cuda(), m2.cuda())
+    assert torch.equal(both, again) and torch.equal(both[1:], one)
