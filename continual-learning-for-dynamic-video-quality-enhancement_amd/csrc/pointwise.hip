@@ -619,6 +619,9 @@ __device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
 // current tile is computed from LDS, so a workgroup always has loads in flight (the one-tile-per-workgroup form spent the
 // whole memory latency of every tile in its staging phase, with only the CU's second workgroup to cover it).
 constexpr int DB_MAXWG = 512;
+// HAS_BN / HAS_EPI: the optional input transform / output epilogue as template parameters - as run-time branches their
+// registers (32 for the BatchNorm parameters) counted against the 128-register budget of every launch.
+template <bool HAS_BN, bool HAS_EPI>
 __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __re
         }
     };
     auto commit = [&](int n) {                                // (optional relu(bn(.))) -> LDS; zero padding stays zero
-        if (bn.mean) {                                        // uniform
+        if constexpr (HAS_BN) {                                        // uniform
             const int c0 = ch0 + 8 * (threadIdx.x & 7);       // this thread's channel group (DB_T % 8 == 0)
             const int g = n / bn.group_images;
             float m[8], is[8], ga[8], be[8];
@@ -699,41 +702,41 @@ __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __re
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         const int gx = tx * DT_W + x;
-        float4 r[3][3];
+        // Input-row stationary: halo row r feeds the three output rows r, r - 1, r - 2 (tap rows 0, 1, 2), so only one row of
+        // the window (3 taps) and three accumulators are live instead of a 3x3 window - the kernel sits at its 128-register
+        // budget (weights 36, prefetched halo pieces 24) and the window's 36 registers pushed the prefetched pieces into
+        // scratch, i.e. made every prefetch wait for its own loads.  Same summation order per output (tap row major).
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;      // output rows r, r - 1, r - 2
+#pragma unroll 1
+        for (int r = 0; r < DT_H + 2; ++r) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) r[a][b] = dw_lds4(xs, a * DT_HW + x + b, c4);
-#pragma unroll
-        for (int y = 0; y < DT_H; ++y) {
-#pragma unroll
-            for (int b = 0; b < 3; ++b) r[2][b] = dw_lds4(xs, (y + 2) * DT_HW + x + b, c4);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const float4 vv = r[a][b], ww = w[a * 3 + b];
-                    acc.x += vv.x * ww.x; acc.y += vv.y * ww.y; acc.z += vv.z * ww.z; acc.w += vv.w * ww.w;
-                }
-            const int gy = ty * DT_H + y;
-            if (gy < H && gx < W) {
-                const size_t pix = (size_t)(n * H + gy) * W + gx;
-                if (ep.add) {
-                    const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
-                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-                }
-                if (ep.mask) {
-                    const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
-                    if (!(m.x > 0.f)) acc.x = 0.f;
-                    if (!(m.y > 0.f)) acc.y = 0.f;
-                    if (!(m.z > 0.f)) acc.z = 0.f;
-                    if (!(m.w > 0.f)) acc.w = 0.f;
-                }
-                stx4(out, pix * out_ld + ch0 + 4 * c4, out_bf16, acc);
+            for (int b = 0; b < 3; ++b) {
+                const float4 vv = dw_lds4(xs, r * DT_HW + x + b, c4);
+                if (r < DT_H) { const float4 ww = w[b]; a0.x += vv.x * ww.x; a0.y += vv.y * ww.y; a0.z += vv.z * ww.z; a0.w += vv.w * ww.w; }
+                if (r >= 1 && r <= DT_H) { const float4 ww = w[3 + b]; a1.x += vv.x * ww.x; a1.y += vv.y * ww.y; a1.z += vv.z * ww.z; a1.w += vv.w * ww.w; }
+                if (r >= 2) { const float4 ww = w[6 + b]; a2.x += vv.x * ww.x; a2.y += vv.y * ww.y; a2.z += vv.z * ww.z; a2.w += vv.w * ww.w; }
             }
-#pragma unroll
-            for (int b = 0; b < 3; ++b) { r[0][b] = r[1][b]; r[1][b] = r[2][b]; }
+            if (r >= 2) {
+                const int y = r - 2;
+                float4 acc = a2;
+                const int gy = ty * DT_H + y;
+                if (gy < H && gx < W) {
+                    const size_t pix = (size_t)(n * H + gy) * W + gx;
+                    if (HAS_EPI && ep.add) {
+                        const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
+                        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                    }
+                    if (HAS_EPI && ep.mask) {
+                        const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
+                        if (!(m.x > 0.f)) acc.x = 0.f;
+                        if (!(m.y > 0.f)) acc.y = 0.f;
+                        if (!(m.z > 0.f)) acc.z = 0.f;
+                        if (!(m.w > 0.f)) acc.w = 0.f;
+                    }
+                    stx4(out, pix * out_ld + ch0 + 4 * c4, out_bf16, acc);
+                }
+            }
+            a2 = a1; a1 = a0; a0 = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();                                      // everyone is done with xs before the next commit
     }
@@ -1186,9 +1189,15 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
         const int ntiles = tilesX * tilesY * N;
         int nwg = ntiles < DB_MAXWG ? ntiles : DB_MAXWG;
         if (nwg >= 8) nwg &= ~7;                              // multiple of the XCD count, see xcd_tile()
-        hipLaunchKernelGGL(dwconv_bf16_kernel, dim3(nwg, C / DB_C), dim3(DB_T), 0,
-                           (hipStream_t)stream, reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W,
-                           tilesX, tilesY, ntiles, flip, out_bf16, make_dwbn(bn, C), ep);
+#define NVQ_DWB(B_, E_)                                                                                                 \
+    hipLaunchKernelGGL((dwconv_bf16_kernel<B_, E_>), dim3(nwg, C / DB_C), dim3(DB_T), 0, (hipStream_t)stream,               \
+                       reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W, tilesX, tilesY, ntiles, flip, \
+                       out_bf16, make_dwbn(bn, C), ep)
+        if (bn && epi) NVQ_DWB(true, true);
+        else if (bn) NVQ_DWB(true, false);
+        else if (epi) NVQ_DWB(false, true);
+        else NVQ_DWB(false, false);
+#undef NVQ_DWB
         return check_launch("dwconv_bf16");
     }
     if (C % DT_C == 0) {
