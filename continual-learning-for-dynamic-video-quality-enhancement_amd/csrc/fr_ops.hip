@@ -505,6 +505,40 @@ __global__ __launch_bounds__(256) void tconv_relayout_kernel(const float* __rest
     else out[gid] = in[(size_t)k * CoCi + i];
 }
 
+// The same (3,1,1) convolution over a TIME-IN-CHANNELS activation [B,H,W,T*Cp] (frame t = channels [t*Cp, t*Cp+C)): out frame
+// t is ONE 1x1 convolution over the contiguous channel range of frames t-1..t+1 with the tap weights laid side by side.
+// transpose == 0: out[r][j*Cp + c] = w[r][c][k0 + j]            (rows r = Co, c < C = Ci: forward / weight-gradient form)
+// transpose == 1: out[r][j*Cp + c] = w[c][r][k0 + nk - 1 - j]   (rows r = Ci, c < C = Co: input-gradient form over dy frames)
+// columns c in [C, Cp) are zero.  w is [Co][Ci][3].
+__global__ __launch_bounds__(256) void tconv_cat_kernel(const float* __restrict__ w, int Co, int Ci, int rows, int C, int Cp,
+                                                        int k0, int nk, int transpose, float* __restrict__ out, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;                       // total = rows * nk * Cp
+    const int c = (int)(gid % Cp);
+    const long q = gid / Cp;
+    const int j = (int)(q % nk), r = (int)(q / nk);
+    float v = 0.f;
+    if (c < C) v = transpose ? w[((size_t)c * Ci + r) * 3 + k0 + nk - 1 - j] : w[((size_t)r * Ci + c) * 3 + k0 + j];
+    out[gid] = v;
+}
+
+// dw[co][ci][k] from the three side-by-side gradient blocks: first (frame 0: taps 1, 2), mid (taps 0, 1, 2; may be null),
+// last (frame T-1: taps 0, 1); each [rows >= Co][ntaps * Cp]
+__global__ __launch_bounds__(256) void tconv_grad_combine_kernel(const float* __restrict__ gf, const float* __restrict__ gm,
+                                                                 const float* __restrict__ gl, int Co, int Ci, int Cp,
+                                                                 float* __restrict__ dw, long total) {
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    if (gid >= total) return;                       // total = Co * Ci * 3
+    const int k = (int)(gid % 3);
+    const long q = gid / 3;
+    const int ci = (int)(q % Ci), co = (int)(q / Ci);
+    float v = 0.f;
+    if (k >= 1) v += gf[(size_t)co * 2 * Cp + (k - 1) * Cp + ci];
+    if (gm) v += gm[(size_t)co * 3 * Cp + k * Cp + ci];
+    if (k <= 1) v += gl[(size_t)co * 2 * Cp + k * Cp + ci];
+    dw[gid] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ small helpers
 // part[n][blk][c] = sum over the blk-th pixel range of image n (input of nvq_cbam_channel).  grid (nblk, N)
 __global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ x, int ld, int C, long HW,
@@ -943,6 +977,24 @@ int nvq_tconv_relayout(const float* in, float* out, int Co, int Ci, int to_taps,
     const long n = (long)Co * Ci;
     hipLaunchKernelGGL(tconv_relayout_kernel, dim3(blocks_for(3 * n)), dim3(256), 0, (hipStream_t)stream, in, out, n, to_taps);
     return check_launch("tconv_relayout");
+}
+
+int nvq_tconv_cat(const float* w, int Co, int Ci, int Cp, int k0, int nk, int transpose, float* out, void* stream) {
+    NVQ_REQUIRE(k0 >= 0 && nk >= 1 && k0 + nk <= 3 && Cp >= (transpose ? Co : Ci), "tconv_cat: taps %d..%d, Cp %d", k0, k0 + nk, Cp);
+    const int rows = transpose ? Ci : Co, C = transpose ? Co : Ci;
+    const long total = (long)rows * nk * Cp;
+    hipLaunchKernelGGL(tconv_cat_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, Co, Ci, rows, C, Cp, k0, nk,
+                       transpose, out, total);
+    return check_launch("tconv_cat");
+}
+
+int nvq_tconv_grad_combine(const float* g_first, const float* g_mid, const float* g_last, int Co, int Ci, int Cp, float* dw,
+                           void* stream) {
+    NVQ_REQUIRE(g_first && g_last && Cp >= Ci, "tconv_grad_combine: args");
+    const long total = (long)Co * Ci * 3;
+    hipLaunchKernelGGL(tconv_grad_combine_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, g_first, g_mid, g_last,
+                       Co, Ci, Cp, dw, total);
+    return check_launch("tconv_grad_combine");
 }
 
 int nvq_gap_blocks(int H, int W) {

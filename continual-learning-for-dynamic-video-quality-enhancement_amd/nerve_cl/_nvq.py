@@ -124,6 +124,8 @@ SIGNATURES = {
     "nvq_depth_space2": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_cast_slice": (ci, [vp, ci, ci, ci, vp, ci, ci, ci, ci, cl, cf, ci, vp]),
     "nvq_tconv_relayout": (ci, [vp, vp, ci, ci, ci, vp]),
+    "nvq_tconv_cat": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "nvq_tconv_grad_combine": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
     "nvq_gap_blocks": (ci, [ci, ci]),
     "nvq_gap_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_add_image_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),

@@ -235,6 +235,153 @@ class TemporalConv(torch.autograd.Function):
         return dx, dw, None, None
 
 
+# ----------------------------------------------------------------------------- (2+1)D convolutions, time-in-channels layout
+# x_tc: [B, H, W, T * Cp] - frame t occupies channels [t * Cp, t * Cp + C), Cp = padc(C, dtype).  BatchNorm3d over such a
+# tensor is BatchNorm over its view [B, H, W * T, Cp]; spatial pooling and element-wise ops do not care.
+class SpatialConvTC(torch.autograd.Function):
+    """nn.Conv3d(Ci, Co, (1,3,3), padding (0,1,1), bias=False) (efficient_layers.py:259-269): the same 3x3 convolution for
+    every frame, reading / writing the frames' channel slices in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, T: int, math: int, out_dtype=None):
+        B, H, W, ld = x.shape
+        Cpi = ld // T
+        Co, Ci = weight.shape[:2]
+        dt = x.dtype if out_dtype is None else out_dtype
+        Cpo = padc(Co, dt)
+        y = _new(x, B, H, W, T * Cpo, dtype=dt)
+        wp = K.conv_pack(weight, False, Cpi, math=math)
+        for t in range(T):
+            K.conv_forward(Sl(x, Cpi, t * Cpi), wp, None, Sl(y, Co, t * Cpo), 3, cout_store=Cpo, math=math)
+        ctx.save_for_backward(x, weight)
+        ctx.T, ctx.math = T, math
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        T, math = ctx.T, ctx.math
+        B, H, W, ld = x.shape
+        Cpi, Cpo = ld // T, dy.shape[-1] // T
+        Co, Ci = weight.shape[:2]
+        dy = dy.contiguous()
+        Cg = Cpo if dy.dtype == torch.bfloat16 else Co
+        full = _new(x, Cg, *weight.shape[1:])
+        ws = _ws(x)
+        for t in range(T):
+            K.conv_wgrad(Sl(x, Cpi, t * Cpi), Ci, Sl(dy, Cg, t * Cpo), full, None, ws, 3, accumulate=t > 0, math=math)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wt = K.conv_pack(weight, True, Cpo, Ci, math=math)
+            for t in range(T):
+                K.conv_forward(Sl(dy, Cpo, t * Cpo), wt, None, Sl(dx, Ci, t * Cpi), 3, cout_store=Cpi, math=math)
+        return dx, full[:Co], None, None, None
+
+
+def _tconv_cat(weight, Cp: int, k0: int, nk: int, transpose: bool) -> torch.Tensor:
+    Co, Ci = weight.shape[:2]
+    rows = Ci if transpose else Co
+    out = _new(weight, rows, nk * Cp, 1, 1)
+    check(lib().nvq_tconv_cat(ptr(weight), Co, Ci, Cp, k0, nk, int(transpose), ptr(out), stream()), "nvq_tconv_cat")
+    return out
+
+
+class TemporalConvTC(torch.autograd.Function):
+    """nn.Conv3d(Ci, Co, (3,1,1), padding (1,0,0), bias=False) (efficient_layers.py:271-278) in the time-in-channels layout:
+    output frame t = one 1x1 convolution over the contiguous channels of frames t-1..t+1 (fewer at the two ends) with the
+    tap weights side by side - every activation is read and written once, nothing is accumulated in memory.  T >= 2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, T: int, math: int):
+        B, H, W, ld = x.shape
+        assert T >= 2 and ld % T == 0
+        Cpi = ld // T
+        Co, Ci = weight.shape[:2]
+        Cpo = padc(Co, x.dtype)
+        y = _new(x, B, H, W, T * Cpo, dtype=x.dtype)
+        forms = {"first": (1, 2), "mid": (0, 3), "last": (0, 2)}          # (first tap, taps) of frame 0 / inner / T-1
+        packs = {k: K.conv_pack(_tconv_cat(weight, Cpi, k0, nk, False), False, nk * Cpi, math=math)
+                 for k, (k0, nk) in forms.items() if k != "mid" or T > 2}
+        for t in range(T):
+            lo, hi = max(t - 1, 0), min(t + 1, T - 1)
+            form = "first" if t == 0 else "last" if t == T - 1 else "mid"
+            K.conv_forward(Sl(x, (hi - lo + 1) * Cpi, lo * Cpi), packs[form], None, Sl(y, Co, t * Cpo), 1, cout_store=Cpo, math=math)
+        ctx.save_for_backward(x, weight)
+        ctx.T, ctx.math = T, math
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        T, math = ctx.T, ctx.math
+        B, H, W, ld = x.shape
+        Cpi, Cpo = ld // T, dy.shape[-1] // T
+        Co, Ci = weight.shape[:2]
+        dy = dy.contiguous()
+        Cg = Cpo if dy.dtype == torch.bfloat16 else Co
+        ws = _ws(x)
+        # weight gradient: one launch per frame into the block of its form; the inner frames accumulate into "mid"
+        g = {"first": _new(x, Cg, 2 * Cpi, 1, 1), "last": _new(x, Cg, 2 * Cpi, 1, 1),
+             "mid": _new(x, Cg, 3 * Cpi, 1, 1) if T > 2 else None}
+        seen = set()
+        for t in range(T):
+            lo, hi = max(t - 1, 0), min(t + 1, T - 1)
+            form = "first" if t == 0 else "last" if t == T - 1 else "mid"
+            nk = hi - lo + 1
+            K.conv_wgrad(Sl(x, nk * Cpi, lo * Cpi), nk * Cpi, Sl(dy, Cg, t * Cpo), g[form], None, ws, 1,
+                         accumulate=form in seen, math=math)
+            seen.add(form)
+        dw = _new(x, *weight.shape)
+        check(lib().nvq_tconv_grad_combine(ptr(g["first"]), ptr(g["mid"]), ptr(g["last"]), Co, Ci, Cpi, ptr(dw), stream()),
+              "nvq_tconv_grad_combine")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dx[t] = sum_k W_k^T dy[t + 1 - k]: a 1x1 conv over the dy frames t-1..t+1, taps in reverse order
+            forms = {"first": (0, 2), "mid": (0, 3), "last": (1, 2)}
+            packs = {k: K.conv_pack(_tconv_cat(weight, Cpo, k0, nk, True), False, nk * Cpo, math=math)
+                     for k, (k0, nk) in forms.items() if k != "mid" or T > 2}
+            for t in range(T):
+                lo, hi = max(t - 1, 0), min(t + 1, T - 1)
+                form = "first" if t == 0 else "last" if t == T - 1 else "mid"
+                K.conv_forward(Sl(dy, (hi - lo + 1) * Cpo, lo * Cpo), packs[form], None, Sl(dx, Ci, t * Cpi), 1, cout_store=Cpi,
+                               math=math)
+        return dx, dw, None, None
+
+
+class GroupMeanTC(torch.autograd.Function):
+    """mean over the T frames of a time-in-channels tensor [B,H,W,T*Cp] -> fp32 [B,H,W,pad4(C)]
+    (AdaptiveAvgPool3d((1,None,None)), frame_recovery.py:137,164-165)"""
+
+    @staticmethod
+    def forward(ctx, x, T: int, C: int):
+        B, H, W, ld = x.shape
+        Cp = ld // T
+        y = _new(x, B, H, W, pad4(C))
+        for t in range(T):
+            cast_slice_(y, x, pad4(C), src_coff=t * Cp, alpha=1.0 / T, accumulate=t > 0)
+        ctx.T, ctx.src = T, (x.dtype, ld, Cp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        T = ctx.T
+        dtype, ld, Cp = ctx.src
+        dy = dy.contiguous()
+        B, H, W, c4 = dy.shape
+        dx = _new(dy, B, H, W, ld, dtype=dtype, zero=Cp > c4)
+        for t in range(T):
+            cast_slice_(dx, dy, c4, dst_coff=t * Cp, alpha=1.0 / T)
+        return dx, None, None
+
+
+def bn_tc(x, mod, T: int, training: bool, relu: bool):
+    """BatchNorm3d over a time-in-channels tensor: statistics over (B, T, H, W) = BatchNorm over the view [B, H, W*T, Cp]"""
+    B, H, W, ld = x.shape
+    return bn(x.view(B, H, W * T, ld // T), mod, training, relu).view(B, H, W, ld)
+
+
 class ConvT(torch.autograd.Function):
     """nn.ConvTranspose2d(Ci, Co, 4, 2, 1, bias=False) (frame_recovery.py:283-304): phase-packed 3x3 conv to 4*Co channels
     + depth-to-space.  weight [Ci, Co, 4, 4]; [N,H,W,ld] -> [N,2H,2W,Co]."""

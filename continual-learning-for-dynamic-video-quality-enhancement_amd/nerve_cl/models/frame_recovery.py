@@ -75,9 +75,16 @@ class TemporalEncoder(_Holder):
         self.temporal_pool = Act()
 
     def forward_nhwc(self, frames: torch.Tensor, T: int, math: int, act_dtype=torch.float32) -> torch.Tensor:
+        """frames: time-major image batch [T*B, H, W, 4]"""
         y = _ops.MaxPool.apply(self.conv1.forward_nhwc(frames, T, math, act_dtype), 2, 2, 0)
         y = _ops.MaxPool.apply(self.conv2.forward_nhwc(y, T, math), 2, 2, 0)
         return _ops.GroupMean.apply(self.conv3.forward_nhwc(y, T, math), T, self.conv3.out_channels)   # fp32 out
+
+    def forward_tc(self, frames_tc: torch.Tensor, T: int, math: int, act_dtype=torch.float32) -> torch.Tensor:
+        """frames_tc: time-in-channels tensor [B, H, W, T*4] (frame t = channels 4t..4t+2); T >= 2"""
+        y = _ops.MaxPool.apply(self.conv1.forward_tc(frames_tc, T, math, act_dtype), 2, 2, 0)
+        y = _ops.MaxPool.apply(self.conv2.forward_tc(y, T, math), 2, 2, 0)
+        return _ops.GroupMeanTC.apply(self.conv3.forward_tc(y, T, math), T, self.conv3.out_channels)    # fp32 out
 
 
 class FusionModule(_Holder):
@@ -194,6 +201,9 @@ class FrameRecoveryNet(BucketedNet):
         bf16 = os.environ.get("NVQ_MATH", "f32").lower() in ("bf16", "bfloat16")
         self.math_mode = _nvq.MATH_BF16 if bf16 else _nvq.MATH_F32
         self.bf16_activations = os.environ.get("NVQ_BF16_ACTIVATIONS", "1") != "0"
+        # temporal encoder layout: True = reference frames side by side in the channel dimension ([B,H,W,T*C]: each (3,1,1)
+        # convolution is one 1x1 convolution per frame, no accumulating passes); False = time-major image batch [T*B,H,W,C]
+        self.time_in_channels = os.environ.get("NVQ_FR_TIME_IN_CHANNELS", "1") != "0"
         self._init_bucket()
 
     # ------------------------------------------------------------------ the layer graph (NHWC, libnvq ops)
@@ -206,10 +216,17 @@ class FrameRecoveryNet(BucketedNet):
         _ops.nchw_to_nhwc_(frame, C * H * W, B, C, H, W, x4, 0)
         _ops.nchw_to_nhwc_(mask, H * W, B, 1, H, W, x4, C)
         sp, _skips = self.spatial_encoder.forward_nhwc(x4, math, act)
-        r = torch.empty(T * B, H, W, 4, dtype=torch.float32, device=frame.device)
-        for t in range(T):                                        # time-major image batch, channel 3 = 0
-            _ops.nchw_to_nhwc_(refs, T * C * H * W, B, C, H, W, r[t * B:(t + 1) * B], 0, czero=4, src_offset=t * C * H * W)
-        tp = self.temporal_encoder.forward_nhwc(r, T, math, act)
+        if T >= 2 and self.time_in_channels:
+            # frames side by side in the channel dimension: the (3,1,1) convolutions become single 1x1 convolutions
+            r = torch.empty(B, H, W, T * 4, dtype=torch.float32, device=frame.device)
+            for t in range(T):
+                _ops.nchw_to_nhwc_(refs, T * C * H * W, B, C, H, W, r, 4 * t, czero=4, src_offset=t * C * H * W)
+            tp = self.temporal_encoder.forward_tc(r, T, math, act)
+        else:
+            r = torch.empty(T * B, H, W, 4, dtype=torch.float32, device=frame.device)
+            for t in range(T):                                    # time-major image batch, channel 3 = 0
+                _ops.nchw_to_nhwc_(refs, T * C * H * W, B, C, H, W, r[t * B:(t + 1) * B], 0, czero=4, src_offset=t * C * H * W)
+            tp = self.temporal_encoder.forward_nhwc(r, T, math, act)
         rec = self.decoder.forward_nhwc(self.fusion.forward_nhwc(sp, tp, math), math, act)
         if rec.shape[1:3] != (H, W):
             rec = _ops.Resize.apply(rec, H, W)

@@ -193,6 +193,15 @@ class TemporalConv3D(_Holder):
         y = _ops.TemporalConv.apply(y, self.temporal[0].weight, T, math)
         return _ops.bn(y, self.temporal[1], self.training, relu=True)
 
+    def forward_tc(self, x: torch.Tensor, T: int, math: int = MATH_F32, act_dtype=None) -> torch.Tensor:
+        """x: time-in-channels tensor [B, H, W, T * Cp] (see nerve_cl._ops); T >= 2.  Every activation is read and written
+        once: no accumulating passes over memory for the temporal taps."""
+        w = self.spatial[0].weight
+        y = _ops.SpatialConvTC.apply(x, w.view(w.shape[0], w.shape[1], 3, 3), T, math, act_dtype)
+        y = _ops.bn_tc(y, self.spatial[1], T, self.training, relu=True)
+        y = _ops.TemporalConvTC.apply(y, self.temporal[0].weight, T, math)
+        return _ops.bn_tc(y, self.temporal[1], T, self.training, relu=True)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,C,T,H,W) -> (B,C',T,H,W)"""
         _nvq.require_device(x, "input")

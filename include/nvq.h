@@ -412,6 +412,15 @@ int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, i
  * weights [3][Co][Ci] (to_taps = 1) and back (its gradient, to_taps = 0): the temporal conv runs as three accumulating
  * 1x1 convolutions over time-shifted image ranges */
 int nvq_tconv_relayout(const float* in, float* out, int Co, int Ci, int to_taps, void* stream);
+/* The same convolution over a time-in-channels activation [B,H,W,T*Cp] (frame t = channels [t*Cp, t*Cp + C)): frame t of the
+ * output is ONE 1x1 convolution over the channels of frames t-1..t+1 with the taps side by side - no accumulating passes.
+ * nvq_tconv_cat lays taps k0 .. k0+nk-1 out as [Co][nk*Cp] (transpose = 0: forward / weight-gradient form) or as
+ * [Ci][nk*Cp] with the tap order reversed (transpose = 1: input-gradient form over dy frames); padding columns are 0.
+ * nvq_tconv_grad_combine folds the gradients of the first-frame (taps 1,2), middle (taps 0..2, may be NULL) and last-frame
+ * (taps 0,1) forms back into dw [Co,Ci,3,1,1]. */
+int nvq_tconv_cat(const float* w, int Co, int Ci, int Cp, int k0, int nk, int transpose, float* out, void* stream);
+int nvq_tconv_grad_combine(const float* g_first, const float* g_mid, const float* g_last, int Co, int Ci, int Cp,
+                           float* dw, void* stream);
 /* per-image partial channel sums [N][nvq_gap_blocks(H,W)][C]: the input of nvq_cbam_channel for a stand-alone CBAM */
 int nvq_gap_blocks(int H, int W);
 int nvq_gap_partial(const float* x, int ld, int C, int N, int H, int W, float* part, void* stream);

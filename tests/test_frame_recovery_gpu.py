@@ -44,11 +44,15 @@ def build(base, T, train):
     return net, P
 
 
+@pytest.mark.parametrize("tic", [True, False], ids=["time_in_channels", "time_major"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_against_reference_fixture_and_oracle(path):
+def test_against_reference_fixture_and_oracle(path, tic):
+    """both layouts of the temporal encoder (FrameRecoveryNet.time_in_channels) against the same fixture"""
     g = np.load(path)
     base, B, T, H, W, train = [int(v) for v in g["cfg"]]
     net, P = build(base, T, bool(train))
+    assert net.time_in_channels                               # the default
+    net.time_in_channels = tic
     corrupted, refs, mask, tgt = inputs(B, T, H, W)
     out = net(corrupted.cuda(), refs.cuda(), mask.cuda())
     loss = F.mse_loss(out, tgt.cuda())

@@ -160,6 +160,44 @@ def test_temporal_conv_3x1x1(T_, B, ci, co):
              [T(co, creal, 3, 1, 1, scale=(3 * creal) ** -0.5)], co)
 
 
+def to_tc(v, Cp):
+    """(B,C,T,H,W) -> time-in-channels [B,H,W,T*Cp] (frame t = channels t*Cp .. t*Cp+C-1, the rest zero); torch ops, so
+    gradients flow back to v"""
+    B, C, T_, H, W = v.shape
+    return F.pad(v.permute(0, 3, 4, 2, 1), (0, Cp - C)).reshape(B, H, W, T_ * Cp).contiguous()
+
+
+def from_tc(y, C, T_):
+    B, H, W, ld = y.shape
+    return y.view(B, H, W, T_, ld // T_)[..., :C].permute(0, 4, 3, 1, 2)
+
+
+@pytest.mark.parametrize("T_,B,ci,co", [(2, 2, 32, 64), (4, 1, 230, 128), (3, 2, 16, 16), (2, 1, 3, 16)])
+def test_2plus1d_convs_time_in_channels(T_, B, ci, co):
+    """the (1,3,3) and (3,1,1) convolutions of TemporalConv3D (reference efficient_layers.py:259-278) on the time-in-channels
+    layout against F.conv3d; mean over time against the mean"""
+    from nerve_cl import _nvq, _ops
+    torch.manual_seed(13)
+    H, W, Cpi, Cpo = 5, 6, (ci + 3) // 4 * 4, (co + 3) // 4 * 4
+    x = T(B, ci, T_, H, W)
+    wt, ws = T(co, ci, 3, 1, 1, scale=(3 * ci) ** -0.5), T(co, ci, 1, 3, 3, scale=(9 * ci) ** -0.5)
+    for name, w, fn, pad in (("temporal", wt, lambda a, b: _ops.TemporalConvTC.apply(a, b, T_, _nvq.MATH_F32), (1, 0, 0)),
+                             ("spatial", ws, lambda a, b: _ops.SpatialConvTC.apply(a, b.view(co, ci, 3, 3), T_, _nvq.MATH_F32), (0, 1, 1))):
+        xg, wg = x.detach().cuda().requires_grad_(True), w.detach().cuda().requires_grad_(True)
+        y = from_tc(fn(to_tc(xg, Cpi), wg), co, T_)
+        r = F.conv3d(x, w, None, padding=pad)
+        assert rel(y, r) < TOL, (name, rel(y, r))
+        d = torch.randn_like(r)
+        y.backward(d.cuda())
+        gx, gw = torch.autograd.grad(r, [x, w], d)
+        assert rel(xg.grad, gx) < TOL and rel(wg.grad, gw) < TOL, (name, rel(xg.grad, gx), rel(wg.grad, gw))
+    xg = x.detach().cuda().requires_grad_(True)
+    m = _ops.GroupMeanTC.apply(to_tc(xg, Cpi), T_, ci)
+    assert rel(m[..., :ci].permute(0, 3, 1, 2), x.mean(2)) < TOL and (m[..., ci:] == 0).all()
+    m.sum().backward()
+    assert rel(xg.grad, torch.full_like(x, 1.0 / T_)) < TOL
+
+
 @pytest.mark.parametrize("Co,H,W", [(16, 32, 48), (64, 21, 17)])
 def test_stem_7x7_stride2(Co, H, W):
     from nerve_cl import _ops
@@ -256,6 +294,10 @@ def test_bf16_storage_variants_of_the_frame_recovery_ops():
     pair(lambda x, w: _ops.Conv.apply(x, w, None, False, _nvq.MATH_BF16), torch.randn(2, 230, 9, 10), 230, torch.randn(128, 230, 1, 1) / 15)
     pair(lambda x, w: _ops.TemporalConv.apply(x, w, 2, _nvq.MATH_BF16), torch.randn(4, 230, 5, 6), 230, torch.randn(128, 230, 3, 1, 1) / 26)
     pair(lambda x, w: _ops.ConvT.apply(x, w, _nvq.MATH_BF16), torch.randn(2, C, 5, 6), C, torch.randn(C, 32, 4, 4) / 16)
+    # time-in-channels (2+1)D convolutions: 2 frames x 64 channels side by side
+    pair(lambda x, w: _ops.TemporalConvTC.apply(x, w, 2, _nvq.MATH_BF16), torch.randn(2, 2 * C, 5, 6), 2 * C, torch.randn(128, C, 3, 1, 1) / 14)
+    pair(lambda x, w: _ops.SpatialConvTC.apply(x, w, 2, _nvq.MATH_BF16), torch.randn(2, 2 * C, 5, 6), 2 * C, torch.randn(128, C, 3, 3) / 24)
+    pair(lambda x: _ops.GroupMeanTC.apply(x, 2, C), torch.randn(2, 2 * C, 5, 6), 2 * C, keeps_dtype=False)
     x4 = torch.randn(2, 4, 20, 24)
     w7 = (torch.randn(16, 4, 7, 7) / 14).cuda()
     a = _ops.Stem7.apply(nhwc(x4), w7, B16)
@@ -291,6 +333,10 @@ def test_standalone_layer_modules_match_the_reference_layers_semantics():
     assert CBAM(64).cuda()(torch.randn(2, 64, 8, 8).cuda()).shape == (2, 64, 8, 8)
     tc = TemporalConv3D(3, 64).cuda()
     assert tc(torch.randn(2, 3, 4, 8, 8).cuda()).shape == (2, 64, 4, 8, 8)
+    v = torch.randn(2, 3, 4, 8, 8)
+    want = tc(v.cuda())                                        # time-major path
+    got = from_tc(tc.forward_tc(to_tc(v.cuda(), 4), 4), 64, 4)  # time-in-channels path, same module
+    assert rel(got, want) < TOL
     corr = LiteFlowNetCorrelation()
     a, b = torch.randn(1, 16, 6, 7), torch.randn(1, 16, 6, 7)
     c = corr(a.cuda(), b.cuda())
