@@ -87,26 +87,33 @@ __global__ void pack_batch_bf16_kernel(const PackJobTable t) {
 // NW: waves per workgroup; each wave owns two tile rows, so the tile is 2*NW x 32 pixels.  NW = 8 (16 rows) stages the
 // weight slab once per 512 pixels instead of 256 and carries 19 % halo instead of 33 %: the kernel is bound by its
 // staging side, and for cout <= 32 the slab is as many bytes as the activations of a 256-pixel tile.
-template <int NB, int KS, bool INB, int NW = 4>
+// CS = 2 (NW = 8): the workgroup's waves split in two halves that compute output channels [0, NT) and [NT, 2 NT) of the SAME
+// 8 x 32 pixel tile (a 64-channel 3x3 conv at the register budget and the four waves per SIMD of the 32-channel kernel: with
+// all 64 channels in one wave the accumulators and the 37 KB weight slab's prefetch registers leave two waves per SIMD).
+template <int NB, int KS, bool INB, int NW = 4, int CS = 1>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX,
                                                                                int tilesY, int nkc, int vec_ok, int dbg) {
-    constexpr int NT = NB * 16;
+    constexpr int NT = NB * 16;                               // output channels of one wave
+    constexpr int NTW = NT * CS;                              // ... of the workgroup (= the packed slab's width)
     constexpr int NTHR = 64 * NW;
-    constexpr int TH_ = 2 * NW;
+    constexpr int TH_ = 2 * NW / CS;
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int HW_ = TW + 2 * HALO;
     constexpr int HH_ = TH_ + 2 * HALO;
     constexpr int NPIX = HW_ * HH_;
-    constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);     // padded slab (see ws_stride_halfs)
+    constexpr int WS_HALFS = ws_stride_halfs(TAPS, NTW);    // padded slab (see ws_stride_halfs)
     constexpr int XITEMS = NPIX * 4;                          // (pixel, 8-channel group) pieces per chunk
     constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;
-    constexpr int WPER = WS_HALFS / 8 / 256;                  // 16-byte pieces per thread of the first 4 waves (exact)
+    constexpr int WTHR = NTHR;                                // every thread moves its share of the weight slab
+    constexpr int WPIECES = WS_HALFS / 8;                     // its 16-byte pieces (a multiple of 256)
+    constexpr int WPER = (WPIECES + WTHR - 1) / WTHR;         // pieces per thread (the last one only where tid + k*WTHR < WPIECES)
     constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
-    constexpr int CT_K = (TAPS / 2) * 4 * NT / 256;           // the centre tap's 4 * NT pieces: register index and
+    constexpr int CT_K = (TAPS / 2) * 4 * NTW / WTHR;         // the centre tap's 4 * NTW pieces: register index and
     constexpr bool LIGHTW = true;
-    constexpr int CT_N = 4 * NT;                              // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
-    static_assert(((TAPS / 2) * 4 * NT) % 256 == 0 && CT_N <= 256, "the centre tap starts a 256-piece row");
+    constexpr int CT_N = 4 * NTW;                             // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
+    static_assert(((TAPS / 2) * 4 * NTW) % WTHR == 0 && CT_N <= 256, "the centre tap starts a WTHR-piece row");
+    static_assert(CS == 1 || (CS == 2 && NW == 8 && NB == 2), "channel-split variant: 8 waves, 2 x 32 channels");
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = CS == 1 ? tid >> 6 : (tid >> 6) & (NW / CS - 1);   // the wave's row pair in the tile
+    const int half = CS == 1 ? 0 : tid >> 8;                  // ... and its half of the workgroup's output channels
     const int c = lane & 15;
     const int g = lane >> 4;
 
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
-    const int cz = blockIdx.y;
+    const int cz = blockIdx.y * CS + half;                    // in units of NT channels (epilogue)
     const int H = d.h, W = d.w;
 
     f32x4 acc[NB][4];
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack) + (size_t)cz * nkc * WS_HALFS;
+    const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack) + (size_t)blockIdx.y * nkc * WS_HALFS;
     const float* in32 = d.in + d.in_coff;
     const __bf16* in16 = reinterpret_cast<const __bf16*>(d.in) + d.in_coff;
 
@@ -162,7 +170,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     u32x4 wr[WPER];
 
     bool cv0 = false, cv1 = false;                            // channel validity of the chunk held in xr
-    auto fetch = [&](int kc) {                                // raw loads only: nothing here may USE a loaded value
+    // `light`: the chunk only has a centre tap (kc < kcl), one tap's 4 * NTW pieces of the slab.  A LITERAL at every call
+    // site: as a run-time condition it makes the weight registers a phi of "loaded" and "kept" values, which the compiler
+    // resolves by loading into temporaries and copying them behind a vmcnt(0) - right after the loads, in front of the MFMA
+    // section: the whole prefetch exposed.  For the same reason every load is unconditional for every thread (a piece past
+    // the slab re-reads the thread's first piece and is not committed).
+    auto fetch = [&](int kc, bool light) {                    // raw loads only: nothing here may USE a loaded value
         const int ch = kc * KCB + chg;
         cv0 = ch < d.cin;
         cv1 = ch + 4 < d.cin;
@@ -181,14 +194,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
         }
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
-        if (LIGHTW && kc < kcl) {                             // centre-tap-only chunk: one tap's 4 * NT pieces (wave-uniform)
-            if (tid < CT_N) wr[CT_K] = wsrc[tid + CT_K * 256];
-        } else if (NW == 4 || tid < 256) {                    // wave-uniform: the slab is 256 x WPER pieces
+        if (light) {
+            wr[CT_K] = wsrc[(tid < CT_N ? tid : 0) + CT_K * WTHR];
+        } else {
 #pragma unroll
-            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * 256];
+            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * WTHR < WPIECES ? tid + k * WTHR : tid];
         }
     };
-    auto commit = [&](int kc) {
+    auto commit = [&](int kc, bool light) {
         const u32x4 z = {0u, 0u, 0u, 0u};
         if (interior) {                                      // workgroup-uniform
 #pragma unroll
@@ -214,11 +227,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
                 }
             }
         }
-        if (LIGHTW && kc < kcl) {
-            if (tid < CT_N) reinterpret_cast<u32x4*>(ws)[tid + CT_K * 256] = wr[CT_K];
-        } else if (NW == 4 || tid < 256) {
+        if (light) {
+            if (tid < CT_N) reinterpret_cast<u32x4*>(ws)[tid + CT_K * WTHR] = wr[CT_K];
+        } else {
 #pragma unroll
-            for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * 256] = wr[k];
+            for (int k = 0; k < WPER; ++k)
+                if ((k + 1) * WTHR <= WPIECES || tid + k * WTHR < WPIECES) reinterpret_cast<u32x4*>(ws)[tid + k * WTHR] = wr[k];
         }
     };
 
@@ -226,40 +240,53 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
     };
     auto ldW = [&](int tap, int cb) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+        return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NTW + half * NT + cb * 16 + c) * 8);
     };
-    auto stage_chunk = [&](int kc) {                          // chunk kc: registers -> LDS, chunk kc + 1: memory -> registers
-        __syncthreads();
-        commit(kc);
-        __syncthreads();
-        if (kc + 1 < nkc && dbg != 2) fetch(kc + 1);
+    // chunk kc: registers -> LDS, chunk kc + 1: memory -> registers.  cl / fl: chunk kc / kc + 1 is a centre-tap-only chunk
+    // (literals, see fetch)
+    auto stage_chunk = [&](int kc, bool cl, bool fl) {
+        if (!(dbg & 16) || kc == 0) __syncthreads();
+        if (!(dbg & 8) || kc == 0) commit(kc, cl);
+        if (!(dbg & 16) || kc == 0) __syncthreads();
+        if (kc + 1 < nkc && !(dbg & 2)) fetch(kc + 1, fl);
+    };
+    auto center_stage = [&]() {                               // the MFMAs of a centre-tap-only chunk
+        bf16x8 p0[2], p1[2], wc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) wc[cb] = ldW(TAPS / 2, cb);
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh) { p0[xh] = ldP(1, xh, 1); p1[xh] = ldP(2, xh, 1); }
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p0[xh], acc[cb][xh], 0, 0, 0);
+                acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p1[xh], acc[cb][2 + xh], 0, 0, 0);
+            }
     };
 
-    fetch(0);
     int kc = 0;
     // Leading chunks whose weights are zero outside the centre tap (nvq_conv_desc::center_cin): one stage instead of nine.
-    // A loop of its own - as a branch inside the main loop it cost the main path 60 VGPRs.
+    // Loops of their own - as a branch inside the main loop the same code cost the main path 60 VGPRs.
     if constexpr (KS == 3) {
-        for (; kc < kcl; ++kc) {
-            stage_chunk(kc);
-            if (dbg == 1) continue;
-            bf16x8 p0[2], p1[2], wc[NB];
-#pragma unroll
-            for (int cb = 0; cb < NB; ++cb) wc[cb] = ldW(TAPS / 2, cb);
-#pragma unroll
-            for (int xh = 0; xh < 2; ++xh) { p0[xh] = ldP(1, xh, 1); p1[xh] = ldP(2, xh, 1); }
-#pragma unroll
-            for (int xh = 0; xh < 2; ++xh)
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb) {
-                    acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p0[xh], acc[cb][xh], 0, 0, 0);
-                    acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p1[xh], acc[cb][2 + xh], 0, 0, 0);
-                }
+        if (kcl > 0) {
+            fetch(0, true);
+            for (; kc + 1 < kcl; ++kc) {
+                stage_chunk(kc, true, true);
+                if (!(dbg & 1)) center_stage();
+            }
+            stage_chunk(kc, true, false);                    // the last of them fetches a full slab
+            if (!(dbg & 1)) center_stage();
+            ++kc;
+        } else {
+            fetch(0, false);
         }
+    } else {
+        fetch(0, false);
     }
     for (; kc < nkc; ++kc) {
-        stage_chunk(kc);
-        if (dbg == 1) continue;
+        stage_chunk(kc, false, false);
+        if (dbg & 1) continue;
         // Fragment reads software-pipelined against the MFMAs (the compiler otherwise emits read -> lgkmcnt(0) ->
         // 4 MFMAs, exposing the LDS latency 2*TAPS times per chunk).  Stages run dx-major, dy-minor: going from dy to
         // dy+1 the wave's upper output row reuses the fragments of the lower one, so a stage needs only the two
@@ -308,10 +335,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     if constexpr (NB >= 2 && 2 * TW * SPX * NW <= NPIX * XSB + WS_HALFS) {
         // full 32 / 64-channel bf16 outputs: stage the tile's output in LDS and store whole pixel rows (64 / 128 B)
         constexpr int PPP = NT / 8;                          // 16-byte pieces per pixel
-        const bool staged = d.out_bf16 && vec_ok && d.cout_store - cz * NT >= NT;
-        if (staged) {                                        // workgroup-uniform
-            __syncthreads();                                 // every wave is done reading xs / ws
-            __bf16* stage = lds + wave * (2 * TW * SPX);
+        const bool can_stage = d.out_bf16 && vec_ok && (CS == 2 || d.cout_store - cz * NT >= NT);   // workgroup-uniform
+        if (can_stage) __syncthreads();                      // every wave is done reading xs / ws
+        if (can_stage && d.cout_store - cz * NT >= NT) {     // (CS = 2: per half of the workgroup)
+            __bf16* stage = lds + (tid >> 6) * (2 * TW * SPX);
             conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage, SPX);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -794,16 +821,23 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
-                           g_debug_mode & 3);
+                           g_debug_mode & ~4);
+        return check_launch("conv_forward_bf16");
+    }
+    // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
+    if (d.ksize == 3 && NT == 64 && d.in_bf16 && !(g_debug_mode & 4)) {
+        const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8, 2>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
+                           g_debug_mode & ~4);
         return check_launch("conv_forward_bf16");
     }
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
 #define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
     do {                                                                                                                 \
         if (d.in_bf16)                                                                                                   \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & ~4);   \
         else                                                                                                             \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);  \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & ~4);  \
     } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);
@@ -816,6 +850,16 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     }
 #undef NVQ_LAUNCH_CONVB
     return check_launch("conv_forward_bf16");
+}
+
+// resident workgroups per CU of the three heaviest kernels as the runtime computes them (tools/kernel_phases.py)
+void conv_occupancy_bf16(int* out) {
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], conv_bf16_kernel<2, 3, true, 8>, 512, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], conv_bf16_kernel<2, 3, true, 8, 2>, 512, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], conv_bf16_kernel<4, 3, true, 4>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[3], rdb_tail_kernel, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[4], wgrad_bf16_kernel<3, true, true, 64, 32>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[5], conv_bf16_kernel<2, 3, true, 4>, 256, 0);
 }
 
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {

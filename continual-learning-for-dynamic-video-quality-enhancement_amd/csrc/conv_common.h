@@ -13,6 +13,7 @@ constexpr int WGRAD_MAX_SLABS = 1024;  // partial slabs (split x 32-ci chunk x 3
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
 void set_conv_debug_mode(int m);
+void conv_occupancy_bf16(int* out);
 
 // NVQ_MATH_BF16 variants (conv_bf16.hip)
 size_t pack_floats_bf16(int cout, int cin_store, int ksize);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
     "nvq_rdb_tail_forward": (ci, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp]),
     "nvq_debug_set_conv_mode": (ci, [ci]),
+    "nvq_debug_conv_occupancy": (ci, [vp]),
     "nvq_rdb_backward_weights_floats": (sz, [ci]),
     "nvq_rdb_backward_weights": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "nvq_sizeof_conv_desc": (sz, []),

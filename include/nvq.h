@@ -121,6 +121,8 @@ int nvq_rdb_tail_forward(const nvq_conv_desc* d3, const nvq_conv_desc* dl, void*
  * 2 = they skip the per-chunk global loads after the first chunk (results are wrong in modes 1 and 2);
  * +4 = the cout <= 32 3x3 kernel uses its 8x32-pixel tiles instead of 16x32 (results unchanged). */
 int nvq_debug_set_conv_mode(int mode);
+/* diagnostics: resident workgroups per CU of conv<2,3,8>, conv<2,3,8,split>, conv<4,3,4>, rdb_tail, wgrad<3,64>, conv<2,3,4> */
+int nvq_debug_conv_occupancy(int* out6);
 size_t nvq_sizeof_conv_desc(void);
 
 /* Combined weights for the backward of one ResidualDenseBlock (super_resolution.py:245-253) in "mirror"

@@ -28,10 +28,11 @@ for cin, cout, k, dt, ld in [(192, 32, 3, torch.bfloat16, l) for l in LDS_] + [(
     def run():
         K.conv_forward(K.Sl(x, cin, 0), wp, b, K.Sl(out, cout, 0), k, relu=True, math=K.MATH_BF16)
     res = []
-    for mode in (0, 1, 2):
+    modes = (0, 1, 2) + tuple(int(m) for m in os.environ.get("PH_MODES", "").split(",") if m)
+    for mode in modes:
         K.lib().nvq_debug_set_conv_mode(mode)
         res.append(timeit(run))
     K.lib().nvq_debug_set_conv_mode(0)
     nbytes = N * H * W * (cin + cout) * (2 if dt == torch.bfloat16 else 4)
     print(f"cin{cin} cout{cout} k{k} ld{ld} {str(dt)[6:]:9s}: normal {res[0]:7.1f} us ({nbytes/res[0]/1e6:6.2f} TB/s alg)  "
-          f"no-mfma {res[1]:7.1f} us  no-loads {res[2]:7.1f} us")
+          f"no-mfma {res[1]:7.1f} us  no-loads {res[2]:7.1f} us  " + "  ".join(f"mode{m} {r:7.1f}" for m, r in zip(modes[3:], res[3:])))
