@@ -245,9 +245,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     // chunk kc: registers -> LDS, chunk kc + 1: memory -> registers.  cl / fl: chunk kc / kc + 1 is a centre-tap-only chunk
     // (literals, see fetch)
     auto stage_chunk = [&](int kc, bool cl, bool fl) {
-        if (!(dbg & 16) || kc == 0) __syncthreads();
-        if (!(dbg & 8) || kc == 0) commit(kc, cl);
-        if (!(dbg & 16) || kc == 0) __syncthreads();
+        __syncthreads();
+        commit(kc, cl);
+        __syncthreads();
         if (kc + 1 < nkc && !(dbg & 2)) fetch(kc + 1, fl);
     };
     auto center_stage = [&]() {                               // the MFMAs of a centre-tap-only chunk
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
         static_assert(2 * TW * STAGE_PX64 * 4 <= NPIX * XSB + WS3, "lff staging tiles fit the LDS stages");
         __syncthreads();                                      // every wave is done with t4 / wl
         __bf16* stage = lds + wave * (2 * TW * STAGE_PX64);
-        conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl, TH, stage, STAGE_PX64);
+        conv_epilogue<NBL, true>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl, TH, stage, STAGE_PX64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __bf16* o16 = reinterpret_cast<__bf16*>(dl.out);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
         }
         return;
     }
-    conv_epilogue<NBL>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
+    conv_epilogue<NBL, true>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -821,23 +821,23 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
-                           g_debug_mode & ~4);
+                           g_debug_mode & 3);
         return check_launch("conv_forward_bf16");
     }
     // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
     if (d.ksize == 3 && NT == 64 && d.in_bf16 && !(g_debug_mode & 4)) {
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8, 2>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
-                           g_debug_mode & ~4);
+                           g_debug_mode & 3);
         return check_launch("conv_forward_bf16");
     }
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
 #define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
     do {                                                                                                                 \
         if (d.in_bf16)                                                                                                   \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & ~4);   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);   \
         else                                                                                                             \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & ~4);  \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);  \
     } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);

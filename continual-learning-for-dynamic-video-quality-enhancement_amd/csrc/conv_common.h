@@ -57,32 +57,105 @@ __device__ __forceinline__ void wgrad_bias_partial(const nvq_wgrad_desc& d, floa
 // A lane's 8-byte pieces of 16 pixels at the tensor's pixel stride are the expensive way to write.
 constexpr int STAGE_PX = 40;   // halfs per staged pixel for 32 output channels (80 B: 16-byte aligned rows)
 constexpr int STAGE_PX64 = 72; // ... for 64 output channels (144 B)
-template <int NB>
+
+// 4 consecutive channels of an fp32 or bf16 tensor as they come from memory (16 or 8 bytes): kept raw until every operand
+// load of the epilogue is in flight - a conversion would be a use, i.e. a wait for that one load.
+typedef unsigned raw4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ raw4 ld_raw4(const float* base, size_t idx, int is_bf16) {
+    raw4 r;
+    if (is_bf16) {
+        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(base) + idx);
+        r[0] = t.x; r[1] = t.y;
+    } else {
+        r = *reinterpret_cast<const raw4*>(base + idx);
+    }
+    return r;
+}
+__device__ __forceinline__ float4 raw4_f(raw4 r, int is_bf16) {
+    if (is_bf16)
+        return make_float4(__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                           __uint_as_float(r[1] & 0xffff0000u));
+    return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+}
+
+// FULL: bias, ReLU bits and the residual of all four pixel blocks are in flight before the first use (needs the registers:
+// 4 NB + 16 NB); otherwise, like the mask always, they are loaded per (pixel block, channel block).
+template <int NB, bool FULL = (NB <= 2)>
 __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&acc)[NB][4], int n, int ty, int tx,
                                               int cz, int wave, int c, int g, int vec_ok, int th = TH,
                                               __bf16* stage = nullptr, int stage_px = STAGE_PX) {
     constexpr int NT = NB * 16;
     const int H = d.h, W = d.w;
+    if (vec_ok) {
+        // ---- phase 1: every operand load (bias, ReLU bits, residual, mask) back to back.  Written load - use - store per
+        // (pixel block, channel block), the stores (which may alias) pin every load behind the previous store: 4 .. 16
+        // memory round trips in a row per tile.  Pixels / channels outside the tensor read element 0 and are not used.
+        bool okp[4];
+        size_t pixv[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-        const int row = 2 * wave + (pb >> 1);
-        const int gy = ty * th + row;
-        const int gx = tx * TW + (pb & 1) * 16 + c;
-        if (gy >= H || gx >= W) continue;        // (the 4 lanes g = 0..3 of a pixel leave together)
-        const size_t pix = (size_t)(n * H + gy) * W + gx;
-        unsigned bits_in = 0, bits_out = 0;
-        if constexpr (NB <= 2) {
-            if (d.bits_mode == 2) bits_in = d.bits[pix];
+        for (int pb = 0; pb < 4; ++pb) {
+            const int gy = ty * th + 2 * wave + (pb >> 1), gx = tx * TW + (pb & 1) * 16 + c;
+            okp[pb] = gy < H && gx < W;                   // (the 4 lanes g = 0..3 of a pixel leave together)
+            pixv[pb] = okp[pb] ? (size_t)(n * H + gy) * W + gx : 0;
         }
+        int cov[NB];
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            const int co = cz * NT + cb * 16 + 4 * g;
-            if (co >= d.cout_store) continue;
-            float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
-            if (vec_ok) {
+        for (int cb = 0; cb < NB; ++cb) cov[cb] = cz * NT + cb * 16 + 4 * g;
+        constexpr int CG = FULL ? NB : 1;                 // channel blocks per load group
+        constexpr int RP = FULL ? 4 : 1;
+        float4 bias4[CG];
+        unsigned bits_in[4];
+        raw4 res4[CG][RP], msk4[CG];
+        auto bias_load = [&](int cb0) {
+#pragma unroll
+            for (int k = 0; k < CG; ++k) bias4[k] = ld4(d.bias + (cov[cb0 + k] < d.cout ? cov[cb0 + k] : 0));
+        };
+        auto res_load = [&](int pb, int cb0, int slot) {
+#pragma unroll
+            for (int k = 0; k < CG; ++k)
+                res4[k][slot] = ld_raw4(d.res, pixv[pb] * d.res_ld + d.res_coff + (cov[cb0 + k] < d.res_cmax ? cov[cb0 + k] : 0),
+                                        d.res_bf16);
+        };
+        if constexpr (NB <= 2) {
+            if (d.bits_mode == 2) {
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) bits_in[pb] = d.bits[pixv[pb]];
+            }
+        }
+        if constexpr (FULL) {
+            if (d.bias) bias_load(0);
+            if (d.res) {
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) res_load(pb, 0, pb);
+            }
+        }
+        // ---- phase 2: arithmetic and stores
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            if (!okp[pb]) continue;
+            const size_t pix = pixv[pb];
+            unsigned bits_out = 0;
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                const int k = cb % CG;
+                if (k == 0) {                              // a new load group
+                    if constexpr (!FULL) {
+                        if (d.bias) bias_load(cb);
+                        if (d.res) res_load(pb, cb, 0);
+                    }
+                    if (d.mask) {
+#pragma unroll
+                        for (int j = 0; j < CG; ++j) {
+                            const bool in = cov[cb + j] >= d.mask_c0 && cov[cb + j] < d.mask_c1;
+                            msk4[j] = ld_raw4(d.mask, pix * d.mask_ld + d.mask_coff + (in ? cov[cb + j] : 0), d.mask_bf16);
+                        }
+                    }
+                }
+                const int co = cov[cb];
+                if (co >= d.cout_store) continue;
+                float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
                 if (d.bias && co < d.cout) {
-                    const float4 b = ld4(d.bias + co);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    v[0] += bias4[k].x; v[1] += bias4[k].y; v[2] += bias4[k].z; v[3] += bias4[k].w;
                 }
                 if (d.relu) {
 #pragma unroll
@@ -93,7 +166,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                 if (d.out2)
                     stx4(d.out2, pix * d.out2_ld + d.out2_coff + co, d.out2_bf16, make_float4(v[0], v[1], v[2], v[3]));
                 if (d.res && co < d.res_cmax) {
-                    const float4 r = ldx4(d.res, pix * d.res_ld + d.res_coff + co, d.res_bf16);
+                    const float4 r = raw4_f(res4[k][RP == 4 ? pb : 0], d.res_bf16);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
                 const size_t oi = pix * d.out_ld + d.out_coff + co;
@@ -102,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                     v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
                 if (d.mask && co >= d.mask_c0 && co < d.mask_c1) {
-                    const float4 m = ldx4(d.mask, pix * d.mask_ld + d.mask_coff + co, d.mask_bf16);
+                    const float4 m = raw4_f(msk4[k], d.mask_bf16);
                     if (!(m.x > 0.f)) v[0] = 0.f;
                     if (!(m.y > 0.f)) v[1] = 0.f;
                     if (!(m.z > 0.f)) v[2] = 0.f;
@@ -112,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                     if (d.bits_mode == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (!((bits_in >> (co + e)) & 1u)) v[e] = 0.f;
+                            if (!((bits_in[pb] >> (co + e)) & 1u)) v[e] = 0.f;
                     } else if (d.bits_mode == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << (co + e);
@@ -123,31 +196,44 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                         (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 else
                     stx4(d.out, oi, d.out_bf16, make_float4(v[0], v[1], v[2], v[3]));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ce = co + e;
-                    if (ce >= d.cout_store) continue;
-                    float x = v[e];
-                    if (d.bias && ce < d.cout) x += d.bias[ce];
-                    if (d.relu) x = fmaxf(x, 0.f);
-                    x *= d.alpha;
-                    if (d.out2) d.out2[pix * d.out2_ld + d.out2_coff + ce] = x;
-                    if (d.res && ce < d.res_cmax) x += d.res[pix * d.res_ld + d.res_coff + ce];
-                    float* op = d.out + pix * d.out_ld + d.out_coff + ce;
-                    if (d.accumulate) x += *op;
-                    if (d.mask && ce >= d.mask_c0 && ce < d.mask_c1 &&
-                        !(d.mask[pix * d.mask_ld + d.mask_coff + ce] > 0.f))
-                        x = 0.f;
-                    *op = x;
+            }
+            if constexpr (NB <= 2) {
+                if (d.bits_mode == 1) {                // OR over the 4 lanes (g) of this pixel, lane g = 0 stores the word
+                    bits_out |= __shfl_xor(bits_out, 16, 64);
+                    bits_out |= __shfl_xor(bits_out, 32, 64);
+                    if (g == 0) d.bits[pix] = bits_out;
                 }
             }
         }
-        if constexpr (NB <= 2) {
-            if (d.bits_mode == 1) {                // OR over the 4 lanes (g) of this pixel, lane g = 0 stores the word
-                bits_out |= __shfl_xor(bits_out, 16, 64);
-                bits_out |= __shfl_xor(bits_out, 32, 64);
-                if (g == 0) d.bits[pix] = bits_out;
+        return;
+    }
+    // ---- scalar path (channel counts / alignments the 16-byte path cannot take)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const int row = 2 * wave + (pb >> 1);
+        const int gy = ty * th + row;
+        const int gx = tx * TW + (pb & 1) * 16 + c;
+        if (gy >= H || gx >= W) continue;
+        const size_t pix = (size_t)(n * H + gy) * W + gx;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int co = cz * NT + cb * 16 + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ce = co + e;
+                if (ce >= d.cout_store) continue;
+                float x = acc[cb][pb][e];
+                if (d.bias && ce < d.cout) x += d.bias[ce];
+                if (d.relu) x = fmaxf(x, 0.f);
+                x *= d.alpha;
+                if (d.out2) d.out2[pix * d.out2_ld + d.out2_coff + ce] = x;
+                if (d.res && ce < d.res_cmax) x += d.res[pix * d.res_ld + d.res_coff + ce];
+                float* op = d.out + pix * d.out_ld + d.out_coff + ce;
+                if (d.accumulate) x += *op;
+                if (d.mask && ce >= d.mask_c0 && ce < d.mask_c1 &&
+                    !(d.mask[pix * d.mask_ld + d.mask_coff + ce] > 0.f))
+                    x = 0.f;
+                *op = x;
             }
         }
     }
