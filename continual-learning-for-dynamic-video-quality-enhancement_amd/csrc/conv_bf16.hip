@@ -110,7 +110,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     constexpr int WPER = (WPIECES + WTHR - 1) / WTHR;         // pieces per thread (the last one only where tid + k*WTHR < WPIECES)
     constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
     constexpr int CT_K = (TAPS / 2) * 4 * NTW / WTHR;         // the centre tap's 4 * NTW pieces: register index and
-    constexpr bool LIGHTW = true;
     constexpr int CT_N = 4 * NTW;                             // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
     static_assert(((TAPS / 2) * 4 * NTW) % WTHR == 0 && CT_N <= 256, "the centre tap starts a WTHR-piece row");
     static_assert(CS == 1 || (CS == 2 && NW == 8 && NB == 2), "channel-split variant: 8 waves, 2 x 32 channels");
@@ -854,12 +853,12 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
 
 // resident workgroups per CU of the three heaviest kernels as the runtime computes them (tools/kernel_phases.py)
 void conv_occupancy_bf16(int* out) {
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], conv_bf16_kernel<2, 3, true, 8>, 512, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], conv_bf16_kernel<2, 3, true, 8, 2>, 512, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], conv_bf16_kernel<4, 3, true, 4>, 256, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[3], rdb_tail_kernel, 256, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[4], wgrad_bf16_kernel<3, true, true, 64, 32>, 256, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[5], conv_bf16_kernel<2, 3, true, 4>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], conv_bf16_kernel<2, 3, true, 8>, 512, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], conv_bf16_kernel<2, 3, true, 8, 2>, 512, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], conv_bf16_kernel<4, 3, true, 4>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[3], rdb_tail_kernel, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[4], wgrad_bf16_kernel<3, true, true, 64, 32>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[5], conv_bf16_kernel<2, 3, true, 4>, 256, 0);
 }
 
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {

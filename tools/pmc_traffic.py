@@ -10,9 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def label_of(kernel_name: str):
     """bench.py's label of a timed launch (nerve_cl/_nvq.py) for a rocprofv3 kernel name, or None"""
-    m = re.search(r"(conv_bf16_kernel|conv_f32_kernel)<(\d+), (\d+)", kernel_name)
+    m = re.search(r"(conv_bf16_kernel|conv_f32_kernel)<(\d+), (\d+)(?:, (?:true|false), (\d+), (\d+))?", kernel_name)
     if m:
-        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+        # conv_bf16_kernel<NB, KS, INB, NW, CS>: a workgroup computes NB * CS blocks of 16 output channels, which is what
+        # bench.py's label counts (the channel-split 64-channel kernel is <2, 3, true, 8, 2> = label <4,3>)
+        nb = int(m.group(2)) * (int(m.group(5)) if m.group(5) else 1)
+        return f"{m.group(1)}<{nb},{m.group(3)}>"
     m = re.search(r"(wgrad_bf16_kernel|wgrad_f32_kernel)<(\d+)", kernel_name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
