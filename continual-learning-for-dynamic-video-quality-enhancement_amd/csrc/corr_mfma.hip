@@ -50,7 +50,10 @@ __device__ __forceinline__ void m_stage_halo(const float* __restrict__ src, int 
     static_assert(ITEMS % M_T == 0, "halo pieces must divide evenly");
     if (src_bf16) {                              // (uniform) bf16-stored source: the pieces are copied as they are
         const __bf16* s16 = reinterpret_cast<const __bf16*>(src);
+        // every load first (clamped addresses), the out-of-image mask applied when the piece is stored: a select right
+        // behind a load is a use of it, i.e. a wait per load - PER memory round trips in a row
         m_u32x4 v[PER];
+        unsigned okm = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int item = threadIdx.x + k * M_T;
@@ -58,35 +61,37 @@ __device__ __forceinline__ void m_stage_halo(const float* __restrict__ src, int 
             const int hy = hp / MHW, hx = hp - hy * MHW;
             const int gy = ty0 + hy - MD, gx = tx0 + hx - MD;
             const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            okm |= (ok ? 1u : 0u) << k;
             v[k] = *reinterpret_cast<const m_u32x4*>(s16 + (ok ? ((size_t)(n * H + gy) * W + gx) * ld + 8 * q : 0));
-            if (!ok) v[k] = (m_u32x4){0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int item = threadIdx.x + k * M_T;
             const int hp = item / PPP, q = item - hp * PPP;
-            *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = v[k];
+            *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = (okm >> k) & 1 ? v[k] : (m_u32x4){0u, 0u, 0u, 0u};
         }
         return;
     }
     float4 a[PER], b[PER];
+    unsigned okm = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {              // loads first (clamped addresses), conversion + stores after
+    for (int k = 0; k < PER; ++k) {              // loads first (clamped addresses), mask + conversion + stores after
         const int item = threadIdx.x + k * M_T;
         const int hp = item / PPP, q = item - hp * PPP;
         const int hy = hp / MHW, hx = hp - hy * MHW;
         const int gy = ty0 + hy - MD, gx = tx0 + hx - MD;
         const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        okm |= (ok ? 1u : 0u) << k;
         const float* p = src + (ok ? ((size_t)(n * H + gy) * W + gx) * ld + 8 * q : 0);
         a[k] = ld4(p);
         b[k] = ld4(p + 4);
-        if (!ok) { a[k] = make_float4(0.f, 0.f, 0.f, 0.f); b[k] = a[k]; }
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int item = threadIdx.x + k * M_T;
         const int hp = item / PPP, q = item - hp * PPP;
-        *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = cvt_f8_bf16(a[k], b[k]);
+        const m_u32x4 v = cvt_f8_bf16(a[k], b[k]);
+        *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = (okm >> k) & 1 ? v : (m_u32x4){0u, 0u, 0u, 0u};
     }
 }
 
@@ -224,22 +229,46 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
         constexpr int ITEMS = DPX * 12;
         constexpr int PER = (ITEMS + M_T - 1) / M_T;
         const __bf16* d16 = reinterpret_cast<const __bf16*>(dcorr);
-#pragma unroll 3
-        for (int k = 0; k < PER; ++k) {
-            const int item = threadIdx.x + k * M_T;
-            if (item >= ITEMS) break;
-            const int dp = item / 12, q = item - dp * 12;
-            int gy, gx;
-            if (WHICH == 1) { gy = ty * MT_H + dp / MT_W; gx = tx * MT_W + dp % MT_W; }
-            else { gy = ty * MT_H + dp / MHW - MD; gx = tx * MT_W + dp % MHW - MD; }
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            m_u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const size_t idx = ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q;
-                if constexpr (D_BF16) v = *reinterpret_cast<const m_u32x4*>(d16 + idx);
-                else v = cvt_f8_bf16(ld4(dcorr + idx), ld4(dcorr + idx + 4));
+        if constexpr (D_BF16) {
+            // bf16 dcorr: all of a thread's pieces in flight, then the stores (written load - store per piece, every load is a
+            // memory round trip of its own: 9 in a row for the halo image)
+            m_u32x4 v[PER];
+            unsigned okm = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int item = threadIdx.x + k * M_T;
+                const int dp = item / 12, q = item - dp * 12;
+                int gy, gx;
+                if (WHICH == 1) { gy = ty * MT_H + dp / MT_W; gx = tx * MT_W + dp % MT_W; }
+                else { gy = ty * MT_H + dp / MHW - MD; gx = tx * MT_W + dp % MHW - MD; }
+                const bool ok = item < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                okm |= (ok ? 1u : 0u) << k;
+                v[k] = *reinterpret_cast<const m_u32x4*>(d16 + (ok ? ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q : 0));
             }
-            *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = v;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int item = threadIdx.x + k * M_T;
+                const int dp = item / 12, q = item - dp * 12;
+                if (item < ITEMS)
+                    *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = (okm >> k) & 1 ? v[k] : (m_u32x4){0u, 0u, 0u, 0u};
+            }
+        } else {
+#pragma unroll 3
+            for (int k = 0; k < PER; ++k) {
+                const int item = threadIdx.x + k * M_T;
+                if (item >= ITEMS) break;
+                const int dp = item / 12, q = item - dp * 12;
+                int gy, gx;
+                if (WHICH == 1) { gy = ty * MT_H + dp / MT_W; gx = tx * MT_W + dp % MT_W; }
+                else { gy = ty * MT_H + dp / MHW - MD; gx = tx * MT_W + dp % MHW - MD; }
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                m_u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    const size_t idx = ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q;
+                    v = cvt_f8_bf16(ld4(dcorr + idx), ld4(dcorr + idx + 4));
+                }
+                *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = v;
+            }
         }
     }
     m_stage_halo<C, YS>(other, other_ld, n % other_images, H, W, ty * MT_H, tx * MT_W, ys, other_bf16);
@@ -287,13 +316,15 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
     if (gy >= H || gx >= W) return;
     const float inv = 1.f / (float)C;
     float* op = dx + ((size_t)(n0 * H + gy) * W + gx) * dx_ld + dx_coff + 4 * g;
+    float4 old[NCB];
+    if (accumulate) {                                        // every read of the read-modify-write before the first store
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) old[cb] = ld4(op + cb * 16);
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
-        if (accumulate) {
-            const float4 o = ld4(op + cb * 16);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
+        if (accumulate) { v.x += old[cb].x; v.y += old[cb].y; v.z += old[cb].z; v.w += old[cb].w; }
         st4(op + cb * 16, v);
     }
 }
