@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     constexpr int CT_N = 4 * NTW;                             // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
     static_assert(((TAPS / 2) * 4 * NTW) % WTHR == 0 && CT_N <= 256, "the centre tap starts a WTHR-piece row");
     static_assert(CS == 1 || (CS == 2 && NW == 8 && NB == 2), "channel-split variant: 8 waves, 2 x 32 channels");
+    static_assert(WPIECES >= WTHR, "a thread's first slab piece exists (the clamp of fetch() relies on it)");
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;

@@ -126,21 +126,58 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
     const float* wp_base = d.wpack + (size_t)cz * nkc * WS_FLOATS;
     const float* in = d.in + d.in_coff;
 
+    // Staging through registers, one chunk ahead (the scheme of the bf16 kernels): chunk kc + 1 is fetched while chunk kc is
+    // multiplied, every load unconditional (out-of-image pieces read element 0 and are zeroed when committed) and all of a
+    // thread's loads in flight at once.  The previous form - load a piece, store it to LDS, next piece - was one memory round
+    // trip per piece, 10 .. 15 in a row per chunk, hidden only by the CU's second workgroup (and not at all on small frames,
+    // where a CU holds one workgroup or none).
+    constexpr int XITEMS = NPIX * 4;                          // (pixel, 4-channel group) pieces per chunk
+    constexpr int XPER = (XITEMS + 255) / 256;
+    constexpr int WS4 = WS_FLOATS / 4;
+    constexpr int WPER = (WS4 + 255) / 256;
+    unsigned xoff[XPER];
+    unsigned xokm = 0;
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+        const int item = tid + k * 256;
+        const int hp = item >> 2;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
+        const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xokm |= (ok ? 1u : 0u) << k;
+        xoff[k] = ok ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld) : 0u;   // (< 2^32 elements: checked on the host)
+    }
+    const int chq = 4 * (tid & 3);                            // channel group of this thread's pieces (256 % 4 == 0)
+    float4 xr[XPER], wr[WPER];
+    bool cv = false;                                          // channel validity of the chunk held in xr
+    auto fetch = [&](int kc) {                                // raw loads only
+        const int ch = kc * KC + chq;
+        cv = ch < d.cin;
+        const unsigned o = cv ? (unsigned)ch : 0u;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) xr[k] = ld4(in + (xoff[k] + o));
+        const float* wsrc = wp_base + (size_t)kc * WS_FLOATS;
+#pragma unroll
+        for (int k = 0; k < WPER; ++k) wr[k] = ld4(wsrc + 4 * (tid + k * 256 < WS4 ? tid + k * 256 : 0));   // (WS4 may be < 256)
+    };
+    auto commit = [&]() {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int item = tid + k * 256;
+            if (item < XITEMS) st4(xs + (item >> 2) * XS_LD + 4 * (item & 3), ((xokm >> k) & 1) && cv ? xr[k] : z);
+        }
+#pragma unroll
+        for (int k = 0; k < WPER; ++k)
+            if ((k + 1) * 256 <= WS4 || tid + k * 256 < WS4) st4(ws + 4 * (tid + k * 256), wr[k]);
+    };
+
+    fetch(0);
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();
-        for (int item = tid; item < NPIX * 4; item += 256) {
-            const int hp = item >> 2, q = item & 3;
-            const int hy = hp / HW_, hx = hp - hy * HW_;
-            const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
-            const int ch = kc * KC + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch < d.cin)
-                v = ld4(in + ((size_t)(n * H + gy) * W + gx) * d.in_ld + ch);
-            st4(xs + hp * XS_LD + 4 * q, v);
-        }
-        const float* wsrc = wp_base + (size_t)kc * WS_FLOATS;
-        for (int i = tid; i < WS_FLOATS / 4; i += 256) st4(ws + 4 * i, ld4(wsrc + 4 * i));
+        commit();
         __syncthreads();
+        if (kc + 1 < nkc) fetch(kc + 1);
 
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -209,22 +246,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
     for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of dy, channels 4*(tid&7)..+3 (bias gradient)
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Staging through registers, one tile ahead, every load unconditional and all of them in flight at once (see
+    // conv_f32_kernel); dy pieces only when whole 4-channel pieces are the rule (cout % 4 == 0), else they are loaded
+    // element-wise when the tile is committed.
+    constexpr int XITEMS = NPIX * 8;
+    constexpr int XPER = (XITEMS + 255) / 256, YPER = TH * TW * 8 / 256;
+    float4 xr[XPER], yr[YPER];
+    unsigned xm = 0, ym = 0;
+    const bool yvec = d.cout % 4 == 0;                        // uniform
+    const int xch = cic * WG_C + 4 * (tid & 7), ych = coc * WG_C + 4 * (tid & 7);   // (256 % 8 == 0)
+    auto fetch = [&](int tile) {
         int bt = xcd_tile(tile, ntiles);
         const int tx = bt % tilesX; bt /= tilesX;
         const int ty = bt % tilesY;
         const int n = bt / tilesY;
-        __syncthreads();
-        for (int item = tid; item < NPIX * 8; item += 256) {
-            const int hp = item >> 3, q = item & 7;
+        xm = 0; ym = 0;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int item = tid + k * 256;
+            const int hp = item >> 3;
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
-            const int ch = cic * WG_C + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W && ch < d.cin)
-                v = ld4(x + ((size_t)(n * H + gy) * W + gx) * d.x_ld + ch);
-            st4(xs + hp * WG_C + ((4 * q) ^ ((hp & 1) << 4)), v);
+            const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch < d.cin;
+            xm |= (ok ? 1u : 0u) << k;
+            xr[k] = ld4(x + (ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + xch : 0));
         }
+        if (yvec) {
+#pragma unroll
+            for (int k = 0; k < YPER; ++k) {
+                const int p = (tid + k * 256) >> 3;
+                const int py = p / TW, px = p - py * TW;
+                const int gy = ty * TH + py, gx = tx * TW + px;
+                const bool ok = gy < H && gx < W && ych < d.cout;
+                ym |= (ok ? 1u : 0u) << k;
+                yr[k] = ld4(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0));
+            }
+        }
+    };
+    auto commit = [&](int tile) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int item = tid + k * 256;
+            const int hp = item >> 3, q = item & 7;
+            if (item < XITEMS) st4(xs + hp * WG_C + ((4 * q) ^ ((hp & 1) << 4)), (xm >> k) & 1 ? xr[k] : z);
+        }
+        if (yvec) {
+#pragma unroll
+            for (int k = 0; k < YPER; ++k) {
+                const int item = tid + k * 256;
+                const int p = item >> 3, q = item & 7;
+                const float4 v = (ym >> k) & 1 ? yr[k] : z;
+                st4(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4)), v);
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            }
+            return;
+        }
+        int bt = xcd_tile(tile, ntiles);
+        const int tx = bt % tilesX; bt /= tilesX;
+        const int ty = bt % tilesY;
+        const int n = bt / tilesY;
         for (int item = tid; item < TH * TW * 8; item += 256) {
             const int p = item >> 3, q = item & 7;
             const int py = p / TW, px = p - py * TW;
@@ -244,7 +325,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
             st4(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4)), v);
             bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
         }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
+        commit(tile);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 
 #pragma unroll 2
         for (int ks = 0; ks < TH * TW / 4; ++ks) {
@@ -562,6 +651,10 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     NVQ_REQUIRE(!d.in_bf16 || (d.cin % 8 == 0 && d.in_ld % 8 == 0 && d.in_coff % 8 == 0),
                 "conv_forward: a bf16 input needs cin, ld, coff %% 8 == 0 (cin %d ld %d coff %d)", d.cin, d.in_ld, d.in_coff);
     if (d.math == NVQ_MATH_BF16) return conv_forward_bf16(d, vec_ok, s);
+    // the kernel keeps per-thread activation offsets as 32-bit element counts
+    NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32),
+                "conv_forward: input tensor of %d x %d x %d x %d elements exceeds the 32-bit offsets of the kernels", d.n, d.h, d.w,
+                d.in_ld);
 #define NVQ_LAUNCH_CONV(NB, KS) \
     hipLaunchKernelGGL((conv_f32_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
     if (d.ksize == 3) {
