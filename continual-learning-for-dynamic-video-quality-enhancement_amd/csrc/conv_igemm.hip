@@ -90,10 +90,14 @@ __global__ void rdb_bwd_weights_kernel(RdbSrc src, int F, float* __restrict__ ou
 }
 
 // ---------------------------------------------------------------- forward / dgrad
-template <int NB, int KS>
+// GS > 1 (small launches: fewer workgroups than the device holds): blockIdx.z = one of GS parts of the packed slab's NT * GS
+// output channels, so that a launch of few tiles still puts a workgroup on every CU - each one re-stages the activation tile
+// and does 1 / GS of the MFMAs.
+template <int NB, int KS, int GS = 1>
 __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d, int tilesX,
                                                            int tilesY, int nkc, int vec_ok) {
-    constexpr int NT = NB * 16;
+    constexpr int NT = NB * 16;                               // output channels of this workgroup
+    constexpr int NTW = NT * GS;                              // ... of the packed slab
     constexpr int HALO = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int HW_ = TW + 2 * HALO;
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
-    const int cz = blockIdx.y;
+    const int part = GS == 1 ? 0 : blockIdx.z;
+    const int cz = blockIdx.y * GS + part;                    // in units of NT channels (epilogue)
     const int H = d.h, W = d.w;
 
     f32x4 acc[NB][4];
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* wp_base = d.wpack + (size_t)cz * nkc * WS_FLOATS;
+    const float* wp_base = d.wpack + (size_t)blockIdx.y * nkc * (WS_FLOATS * GS);
     const float* in = d.in + d.in_coff;
 
     // Staging through registers, one chunk ahead (the scheme of the bf16 kernels): chunk kc + 1 is fetched while chunk kc is
@@ -156,9 +161,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
         const unsigned o = cv ? (unsigned)ch : 0u;
 #pragma unroll
         for (int k = 0; k < XPER; ++k) xr[k] = ld4(in + (xoff[k] + o));
-        const float* wsrc = wp_base + (size_t)kc * WS_FLOATS;
+        const float* wsrc = wp_base + (size_t)kc * (WS_FLOATS * GS);
 #pragma unroll
-        for (int k = 0; k < WPER; ++k) wr[k] = ld4(wsrc + 4 * (tid + k * 256 < WS4 ? tid + k * 256 : 0));   // (WS4 may be < 256)
+        for (int k = 0; k < WPER; ++k) {
+            const int i = tid + k * 256 < WS4 ? tid + k * 256 : 0;                      // (WS4 may be < 256)
+            wr[k] = ld4(wsrc + 4 * (GS == 1 ? i : (i / NT) * NTW + part * NT + i % NT));   // this part's NT columns of each row
+        }
     };
     auto commit = [&]() {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -655,17 +663,28 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32),
                 "conv_forward: input tensor of %d x %d x %d x %d elements exceeds the 32-bit offsets of the kernels", d.n, d.h, d.w,
                 d.in_ld);
-#define NVQ_LAUNCH_CONV(NB, KS) \
-    hipLaunchKernelGGL((conv_f32_kernel<NB, KS>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
-    if (d.ksize == 3) {
-        if (NT == 16) NVQ_LAUNCH_CONV(1, 3);
-        else if (NT == 32) NVQ_LAUNCH_CONV(2, 3);
-        else NVQ_LAUNCH_CONV(4, 3);
-    } else {
-        if (NT == 16) NVQ_LAUNCH_CONV(1, 1);
-        else if (NT == 32) NVQ_LAUNCH_CONV(2, 1);
-        else NVQ_LAUNCH_CONV(4, 1);
-    }
+    // small launches: split the slab's output channels over GS workgroups per tile until the device's ~512 resident
+    // workgroups are covered (BASELINE configs[0] / [4]: 8 .. 16 clips of 64x64 are 128 .. 256 tiles)
+    int gs = 1;
+    while (gs * 2 <= NT / 16 && (long)grid.x * grid.y * gs * 2 <= 512) gs *= 2;
+    const dim3 gridz(grid.x, grid.y, gs);
+#define NVQ_LAUNCH_CONV(NB, KS, GS) \
+    hipLaunchKernelGGL((conv_f32_kernel<NB, KS, GS>), gridz, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok)
+#define NVQ_LAUNCH_CONV_KS(KS)                                       \
+    do {                                                             \
+        if (NT == 16) NVQ_LAUNCH_CONV(1, KS, 1);                     \
+        else if (NT == 32) {                                         \
+            if (gs == 1) NVQ_LAUNCH_CONV(2, KS, 1);                  \
+            else NVQ_LAUNCH_CONV(1, KS, 2);                          \
+        } else {                                                     \
+            if (gs == 1) NVQ_LAUNCH_CONV(4, KS, 1);                  \
+            else if (gs == 2) NVQ_LAUNCH_CONV(2, KS, 2);             \
+            else NVQ_LAUNCH_CONV(1, KS, 4);                          \
+        }                                                            \
+    } while (0)
+    if (d.ksize == 3) NVQ_LAUNCH_CONV_KS(3);
+    else NVQ_LAUNCH_CONV_KS(1);
+#undef NVQ_LAUNCH_CONV_KS
 #undef NVQ_LAUNCH_CONV
     return check_launch("conv_forward");
 }
