@@ -153,31 +153,32 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const nvq_conv_desc d,
         xoff[k] = ok ? (unsigned)(((size_t)(n * H + gy) * W + gx) * d.in_ld) : 0u;   // (< 2^32 elements: checked on the host)
     }
     const int chq = 4 * (tid & 3);                            // channel group of this thread's pieces (256 % 4 == 0)
-    float4 xr[XPER], wr[WPER];
+    f32x4 xr[XPER], wr[WPER];                                 // (ext_vector types: HIP's float4 struct is copied around behind waits)
     bool cv = false;                                          // channel validity of the chunk held in xr
     auto fetch = [&](int kc) {                                // raw loads only
         const int ch = kc * KC + chq;
         cv = ch < d.cin;
         const unsigned o = cv ? (unsigned)ch : 0u;
 #pragma unroll
-        for (int k = 0; k < XPER; ++k) xr[k] = ld4(in + (xoff[k] + o));
+        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const f32x4*>(in + (xoff[k] + o));
         const float* wsrc = wp_base + (size_t)kc * (WS_FLOATS * GS);
 #pragma unroll
         for (int k = 0; k < WPER; ++k) {
             const int i = tid + k * 256 < WS4 ? tid + k * 256 : 0;                      // (WS4 may be < 256)
-            wr[k] = ld4(wsrc + 4 * (GS == 1 ? i : (i / NT) * NTW + part * NT + i % NT));   // this part's NT columns of each row
+            wr[k] = *reinterpret_cast<const f32x4*>(wsrc + 4 * (GS == 1 ? i : (i / NT) * NTW + part * NT + i % NT));   // this part's NT columns
         }
     };
     auto commit = [&]() {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
-            if (item < XITEMS) st4(xs + (item >> 2) * XS_LD + 4 * (item & 3), ((xokm >> k) & 1) && cv ? xr[k] : z);
+            if (item < XITEMS)
+                *reinterpret_cast<f32x4*>(xs + (item >> 2) * XS_LD + 4 * (item & 3)) = ((xokm >> k) & 1) && cv ? xr[k] : z;
         }
 #pragma unroll
         for (int k = 0; k < WPER; ++k)
-            if ((k + 1) * 256 <= WS4 || tid + k * 256 < WS4) st4(ws + 4 * (tid + k * 256), wr[k]);
+            if ((k + 1) * 256 <= WS4 || tid + k * 256 < WS4) *reinterpret_cast<f32x4*>(ws + 4 * (tid + k * 256)) = wr[k];
     };
 
     fetch(0);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
     // element-wise when the tile is committed.
     constexpr int XITEMS = NPIX * 8;
     constexpr int XPER = (XITEMS + 255) / 256, YPER = TH * TW * 8 / 256;
-    float4 xr[XPER], yr[YPER];
+    f32x4 xr[XPER], yr[YPER];                                 // (ext_vector types, see conv_f32_kernel)
     unsigned xm = 0, ym = 0;
     const bool yvec = d.cout % 4 == 0;                        // uniform
     const int xch = cic * WG_C + 4 * (tid & 7), ych = coc * WG_C + 4 * (tid & 7);   // (256 % 8 == 0)
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
             const int gy = ty * TH + hy - HALO, gx = tx * TW + hx - HALO;
             const bool ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && xch < d.cin;
             xm |= (ok ? 1u : 0u) << k;
-            xr[k] = ld4(x + (ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + xch : 0));
+            xr[k] = *reinterpret_cast<const f32x4*>(x + (ok ? ((size_t)(n * H + gy) * W + gx) * d.x_ld + xch : 0));
         }
         if (yvec) {
 #pragma unroll
@@ -287,26 +288,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
                 const int gy = ty * TH + py, gx = tx * TW + px;
                 const bool ok = gy < H && gx < W && ych < d.cout;
                 ym |= (ok ? 1u : 0u) << k;
-                yr[k] = ld4(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0));
+                yr[k] = *reinterpret_cast<const f32x4*>(dy + (ok ? ((size_t)(n * H + gy) * W + gx) * d.dy_ld + ych : 0));
             }
         }
     };
     auto commit = [&](int tile) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < XPER; ++k) {
             const int item = tid + k * 256;
             const int hp = item >> 3, q = item & 7;
-            if (item < XITEMS) st4(xs + hp * WG_C + ((4 * q) ^ ((hp & 1) << 4)), (xm >> k) & 1 ? xr[k] : z);
+            if (item < XITEMS) *reinterpret_cast<f32x4*>(xs + hp * WG_C + ((4 * q) ^ ((hp & 1) << 4))) = (xm >> k) & 1 ? xr[k] : z;
         }
         if (yvec) {
 #pragma unroll
             for (int k = 0; k < YPER; ++k) {
                 const int item = tid + k * 256;
                 const int p = item >> 3, q = item & 7;
-                const float4 v = (ym >> k) & 1 ? yr[k] : z;
-                st4(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4)), v);
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+                const f32x4 v = (ym >> k) & 1 ? yr[k] : z;
+                *reinterpret_cast<f32x4*>(dys + p * WG_C + ((4 * q) ^ ((p & 1) << 4))) = v;
+                bsum.x += v[0]; bsum.y += v[1]; bsum.z += v[2]; bsum.w += v[3];
             }
             return;
         }
