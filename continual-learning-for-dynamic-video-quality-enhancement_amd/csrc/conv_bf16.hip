@@ -106,14 +106,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     constexpr int XITEMS = NPIX * 4;                          // (pixel, 8-channel group) pieces per chunk
     constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;
     constexpr int WTHR = NTHR;                                // every thread moves its share of the weight slab
-    constexpr int WPIECES = WS_HALFS / 8;                     // its 16-byte pieces (a multiple of 256)
+    constexpr int WPIECES = TAPS * 4 * NTW;                   // its 16-byte pieces that carry weights (the packed slab is padded)
     constexpr int WPER = (WPIECES + WTHR - 1) / WTHR;         // pieces per thread (the last one only where tid + k*WTHR < WPIECES)
     constexpr int XREGS = INB ? 1 : 2;                        // 16-byte registers per 8-channel piece
     constexpr int CT_K = (TAPS / 2) * 4 * NTW / WTHR;         // the centre tap's 4 * NTW pieces: register index and
     constexpr int CT_N = 4 * NTW;                             // thread count (NT = 16: pieces 256..319, 32: 512..639, 64: 1024..1279)
     static_assert(((TAPS / 2) * 4 * NTW) % WTHR == 0 && CT_N <= 256, "the centre tap starts a WTHR-piece row");
     static_assert(CS == 1 || (CS == 2 && NW == 8 && NB == 2), "channel-split variant: 8 waves, 2 x 32 channels");
-    static_assert(WPIECES >= WTHR, "a thread's first slab piece exists (the clamp of fetch() relies on it)");
+
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XSB;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     // site: as a run-time condition it makes the weight registers a phi of "loaded" and "kept" values, which the compiler
     // resolves by loading into temporaries and copying them behind a vmcnt(0) - right after the loads, in front of the MFMA
     // section: the whole prefetch exposed.  For the same reason every load is unconditional for every thread (a piece past
-    // the slab re-reads the thread's first piece and is not committed).
+    // the slab reads piece 0 and is not committed).
     auto fetch = [&](int kc, bool light) {                    // raw loads only: nothing here may USE a loaded value
         const int ch = kc * KCB + chg;
         cv0 = ch < d.cin;
@@ -198,7 +198,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             wr[CT_K] = wsrc[(tid < CT_N ? tid : 0) + CT_K * WTHR];
         } else {
 #pragma unroll
-            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * WTHR < WPIECES ? tid + k * WTHR : tid];
+            // (a piece past the slab: every such lane reads piece 0 - ONE 16-byte request per wave; what a workgroup ingests per
+            // chunk is what bounds these kernels, and distinct dummy addresses were 10 % of it)
+            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * WTHR < WPIECES ? tid + k * WTHR : 0];
         }
     };
     auto commit = [&](int kc, bool light) {
