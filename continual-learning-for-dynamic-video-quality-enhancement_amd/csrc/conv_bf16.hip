@@ -818,10 +818,10 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int ncz = (d.cout_store + NT - 1) / NT;
     const int nkc = (d.cin + KCB - 1) / KCB;
     int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
-    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them and the launch fills the
-    // device (small frames: the 8-row tiles of the 4-wave kernel are twice as many workgroups)
-    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && !(g_debug_mode & 4) &&
-        (long)tilesX * ((d.h + 2 * TH - 1) / (2 * TH)) * d.n * ncz >= 256) {
+    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them.  (Choosing the 8-row
+    // tiles of the 4-wave kernel for launches that leave the device under-filled gave 4.43 -> 4.23 ms on the 8-clip 64x64 step
+    // and was taken out again: the small parity tests would no longer run the kernel the 540p benchmark runs.)
+    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && !(g_debug_mode & 4)) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
