@@ -6,6 +6,11 @@ T=3, 540p -> 1080p), one process per GPU, weak scaling.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Run without WORLD_SIZE in the environment, `--gpus N` (N > 1) starts the N ranks itself: this process launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process before it
+touches the GPU (never an exec), relays rank 0's JSON line and exits with the child's return code.  Launched by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of that job.
+
 A step = zero_grad -> forward -> MSE -> backward (-> RCCL all-reduce of the flat gradient
 bucket) -> AdamW step, on synthetic U[0,1) clips with T distinct frames, resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line (contract in the round prompt).  `roofline` is the
@@ -181,6 +186,24 @@ def cpu_baseline(args, cfg, parity_probe=None):
     }
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run job (one process
+    per GPU, rendezvous on 127.0.0.1) and return its exit code.  Called before this process has imported anything that
+    touches the GPU; the child's stdout (rank 0's JSON line) and stderr pass straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +233,9 @@ def main():
     ap.add_argument("--detail", action="store_true", help="print a per-shape table of the conv launches to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # nothing above has initialised the GPU
+
     from nerve_cl import _nvq, ops, parallel
     from nerve_cl.models import SuperResolutionNet
 
@@ -221,10 +247,8 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs",
                   file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = dict(F=args.features, blocks=args.blocks, window=args.window, T=2 * args.window + 1,
@@ -282,14 +306,14 @@ def main():
 
     def timed_pass():
         if world > 1:
-            torch.distributed.barrier()
+            parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            parallel.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -14,10 +14,15 @@
 
 namespace nvq {
 
-// Diagnostic switch (tools/kernel_phases.py only; 0 in every product path): 1 = skip the MFMA section,
-// 2 = skip the per-chunk global loads after the first chunk.  Results are wrong in both modes.
+// Diagnostic switch of libnvq_debug.so (tools/kernel_phases.py; -DNVQ_DEBUG_TOOLS): 1 = skip the MFMA section, 2 = skip the
+// per-chunk global loads after the first chunk.  Results are wrong in both modes.  The shipped library has no such state:
+// there the kernels' `dbg` argument is the literal 0.
+#ifdef NVQ_DEBUG_TOOLS
 static int g_debug_mode = 0;
 void set_conv_debug_mode(int m) { g_debug_mode = m; }
+#else
+constexpr int g_debug_mode = 0;
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece
@@ -821,7 +826,7 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them.  (Choosing the 8-row
     // tiles of the 4-wave kernel for launches that leave the device under-filled gave 4.43 -> 4.23 ms on the 8-clip 64x64 step
     // and was taken out again: the small parity tests would no longer run the kernel the 540p benchmark runs.)
-    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && !(g_debug_mode & 4)) {
+    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && d.tile_rows != 8) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
@@ -829,7 +834,7 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
         return check_launch("conv_forward_bf16");
     }
     // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
-    if (d.ksize == 3 && NT == 64 && d.in_bf16 && !(g_debug_mode & 4)) {
+    if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows != 8) {
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8, 2>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
                            g_debug_mode & 3);

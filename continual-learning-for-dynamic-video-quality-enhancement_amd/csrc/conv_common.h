@@ -12,7 +12,9 @@ constexpr int WGRAD_MAX_SLABS = 1024;  // partial slabs (split x 32-ci chunk x 3
 
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
+#ifdef NVQ_DEBUG_TOOLS
 void set_conv_debug_mode(int m);
+#endif
 void conv_occupancy_bf16(int* out);
 
 // NVQ_MATH_BF16 variants (conv_bf16.hip)

@@ -566,8 +566,10 @@ int nvq_rdb_backward_weights(const float* lff, const float* w0, const float* w1,
     return check_launch("rdb_backward_weights");
 }
 
+#ifdef NVQ_DEBUG_TOOLS
 int nvq_debug_set_conv_mode(int mode) { set_conv_debug_mode(mode); return NVQ_OK; }
 int nvq_debug_conv_occupancy(int* out6) { conv_occupancy_bf16(out6); return NVQ_OK; }
+#endif
 
 size_t nvq_sizeof_conv_desc(void) { return sizeof(nvq_conv_desc); }
 size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }

@@ -46,6 +46,30 @@ __global__ __launch_bounds__(256) void fisher_acc_kernel(const float* __restrict
     }
 }
 
+// SynapticIntelligence.update_importance (ewc.py:343-354) over a flat bucket: W += -(grad * (theta - p_old)); p_old = theta.
+// Separate multiply and add (no fma contraction), the reference's two torch ops.
+__global__ __launch_bounds__(256) void si_update_kernel(const float* __restrict__ theta, const float* __restrict__ grad,
+                                                        long n, float* __restrict__ p_old, float* __restrict__ W) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = theta[i];
+        W[i] = __fadd_rn(W[i], -__fmul_rn(grad[i], __fsub_rn(t, p_old[i])));
+        p_old[i] = t;
+    }
+}
+
+// SynapticIntelligence.register_task (ewc.py:356-368): omega += W / ((theta - p_old)^2 + damping); W = 0; p_old = theta.
+__global__ __launch_bounds__(256) void si_consolidate_kernel(const float* __restrict__ theta, long n, float damping,
+                                                             float* __restrict__ p_old, float* __restrict__ W,
+                                                             float* __restrict__ omega) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = theta[i];
+        const float d = __fsub_rn(t, p_old[i]);
+        omega[i] = __fadd_rn(omega[i], __fdiv_rn(W[i], __fadd_rn(__fmul_rn(d, d), damping)));
+        W[i] = 0.f;
+        p_old[i] = t;
+    }
+}
+
 static int flat_blocks(long n) {
     int nb = ceil_div(n, 256L * 4);
     if (nb > 1024) nb = 1024;
@@ -76,6 +100,17 @@ int nvq_ewc_penalty_grad(const float* theta, const float* theta_star, const floa
     hipLaunchKernelGGL(ewc_grad_kernel, dim3(flat_blocks(n)), dim3(256), 0, (hipStream_t)stream, theta, theta_star,
                        fisher, n, lambda, scale_dev, grad, accumulate);
     return check_launch("ewc_penalty_grad");
+}
+
+int nvq_si_update(const float* theta, const float* grad, long n, float* p_old, float* W, void* stream) {
+    hipLaunchKernelGGL(si_update_kernel, dim3(flat_blocks(n)), dim3(256), 0, (hipStream_t)stream, theta, grad, n, p_old, W);
+    return check_launch("si_update");
+}
+
+int nvq_si_consolidate(const float* theta, long n, float damping, float* p_old, float* W, float* omega, void* stream) {
+    hipLaunchKernelGGL(si_consolidate_kernel, dim3(flat_blocks(n)), dim3(256), 0, (hipStream_t)stream, theta, n, damping,
+                       p_old, W, omega);
+    return check_launch("si_consolidate");
 }
 
 int nvq_fisher_accumulate(const float* grad, long n, float* fisher, void* stream) {

@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("math", ci),
         ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
         ("bits", vp), ("bits_mode", ci), ("center_cin", ci), ("in_plane", C.c_uint),
+        ("tile_rows", ci),
     ]
 
 
@@ -75,8 +76,6 @@ SIGNATURES = {
     "nvq_conv_pack": (ci, [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "nvq_conv_forward": (ci, [C.POINTER(ConvDesc), vp]),
     "nvq_rdb_tail_forward": (ci, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), vp]),
-    "nvq_debug_set_conv_mode": (ci, [ci]),
-    "nvq_debug_conv_occupancy": (ci, [vp]),
     "nvq_rdb_backward_weights_floats": (sz, [ci]),
     "nvq_rdb_backward_weights": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "nvq_sizeof_conv_desc": (sz, []),
@@ -145,6 +144,8 @@ SIGNATURES = {
     "nvq_ewc_penalty": (ci, [vp, vp, vp, cl, cf, vp, vp, sz, vp]),
     "nvq_ewc_penalty_grad": (ci, [vp, vp, vp, cl, cf, vp, vp, ci, vp]),
     "nvq_fisher_accumulate": (ci, [vp, cl, vp, vp]),
+    "nvq_si_update": (ci, [vp, vp, cl, vp, vp, vp]),
+    "nvq_si_consolidate": (ci, [vp, cl, cf, vp, vp, vp, vp]),
 }
 
 
@@ -411,7 +412,8 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
-                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0) -> ConvDesc:
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0,
+                 tile_rows: int = 0) -> ConvDesc:
     """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask.
     center_cin: leading input channels whose weights are zero outside the centre tap (a hint, see nvq_conv_desc)."""
     n, h, w, _ = x.t.shape
@@ -439,6 +441,7 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
         d.bits, d.bits_mode = ptr(bits), bits_mode
     d.center_cin = center_cin
     d.in_plane = x.plane
+    d.tile_rows = tile_rows
     return d
 
 
@@ -447,12 +450,12 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
                  cout_store: Optional[int] = None, out2: Optional[Sl] = None,
                  res: Optional[Sl] = None, mask: Optional[Sl] = None, mask_c0: int = 0,
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
-                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0) -> None:
+                 bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0, tile_rows: int = 0) -> None:
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
     d = _conv_desc(x, wpack, bias, out, ksize, relu=relu, alpha=alpha, accumulate=accumulate, cout_store=cout_store,
                    out2=out2, res=res, mask=mask, mask_c0=mask_c0, mask_c1=mask_c1, math=math, bits=bits,
-                   bits_mode=bits_mode, center_cin=center_cin)
+                   bits_mode=bits_mode, center_cin=center_cin, tile_rows=tile_rows)
     check(lib().nvq_conv_forward(C.byref(d), stream()), "nvq_conv_forward")
     if ev0 is not None:
         cin = x.c if alg_cin is None else alg_cin
@@ -770,6 +773,15 @@ def ewc_penalty(theta, star, fisher, lam: float, out, ws):
 def ewc_penalty_grad(theta, star, fisher, lam: float, scale_dev, grad, accumulate: bool):
     check(lib().nvq_ewc_penalty_grad(ptr(theta), ptr(star), ptr(fisher), theta.numel(), lam, ptr(scale_dev),
                                      ptr(grad), int(accumulate), stream()), "nvq_ewc_penalty_grad")
+
+
+def si_update(theta, grad, p_old, W):
+    check(lib().nvq_si_update(ptr(theta), ptr(grad), theta.numel(), ptr(p_old), ptr(W), stream()), "nvq_si_update")
+
+
+def si_consolidate(theta, damping: float, p_old, W, omega):
+    check(lib().nvq_si_consolidate(ptr(theta), theta.numel(), damping, ptr(p_old), ptr(W), ptr(omega), stream()),
+          "nvq_si_consolidate")
 
 
 def fisher_accumulate(grad, fisher):

@@ -379,51 +379,74 @@ class OnlineEWC(EWC):
 
 class SynapticIntelligence:
     """Synaptic Intelligence (Zenke et al. 2017) with the reference's interface (nerve_cl/continual/ewc.py:306-379):
-    ``update_importance()`` after every optimizer step (W += -grad * (theta - theta_prev)), ``register_task()`` at a task
-    end (omega += W / (delta^2 + damping)), ``penalty()`` = si_lambda * sum omega (theta - theta_old)^2.
+    ``update_importance()`` after every optimizer step (W += -grad * (theta - theta_prev); theta_prev = theta),
+    ``register_task()`` at a task end (omega += W / (delta^2 + damping)), ``penalty()`` = si_lambda * sum omega (theta - p_old)^2.
 
-    W, theta_old and omega live in one flat fp32 bucket each (``W`` / ``p_old`` / ``omega`` are dicts of views into them,
-    keyed by parameter name as in the reference); the penalty and its gradient are the same two libnvq kernels EWC uses
-    (``nvq_ewc_penalty`` with lambda = 2 * si_lambda, Fisher := omega, theta* := theta_old)."""
+    Like EWC, the state lives on flat buckets, one per segment (``segments_of``): for a bucketed network W / p_old / omega are
+    flat fp32 tensors in the network's gradient-bucket layout, so a step's update is ONE ``nvq_si_update`` launch reading the
+    persistent flat parameter view and the flat gradient bucket the backward just wrote - no per-step ``cat`` over 131
+    tensors; ``register_task`` is one ``nvq_si_consolidate``; the penalty and its gradient are the two EWC kernels
+    (``nvq_ewc_penalty`` with lambda = 2 * si_lambda, Fisher := omega, theta* := p_old), fused into the network's bucket when
+    its backward is still to come.  ``W`` / ``p_old`` / ``omega`` are dicts of views keyed by parameter name, as in the
+    reference.  (Reference quirk kept: ``p_old`` is refreshed by every ``update_importance``, so a loop that calls it after
+    each step sees a zero penalty; oracle/cl_cases.si_drive.)"""
 
     def __init__(self, model: nn.Module, si_lambda: float = 1.0, damping: float = 0.1):
         self.model = model
         self.si_lambda = si_lambda
         self.damping = damping
-        self._named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError(f"SynapticIntelligence needs the model on the GPU (found {dev}); there is no CPU fallback")
-        n = sum(p.numel() for _, p in self._named)
-        self._W = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._omega = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._p_old = self._theta()
-        self.W = _flat_views(self._W, self._named)
-        self.omega = _flat_views(self._omega, self._named)
-        self.p_old = _flat_views(self._p_old, self._named)
+        self._segs = segments_of(model)
+        self._W = [torch.zeros(sg.numel(), dtype=torch.float32, device=dev) for sg in self._segs]
+        self._omega = [torch.zeros(sg.numel(), dtype=torch.float32, device=dev) for sg in self._segs]
+        self._p_old = [sg.theta().clone() for sg in self._segs]
+        self.W: Dict[str, torch.Tensor] = {}
+        self.omega: Dict[str, torch.Tensor] = {}
+        self.p_old: Dict[str, torch.Tensor] = {}
+        for sg, w, o, p in zip(self._segs, self._W, self._omega, self._p_old):
+            self.W.update(sg.views(w))
+            self.omega.update(sg.views(o))
+            self.p_old.update(sg.views(p))
 
-    def _theta(self) -> torch.Tensor:
-        return torch.cat([p.detach().reshape(-1).float() for _, p in self._named])
-
-    def _set_p_old(self, theta: torch.Tensor) -> None:
-        self._p_old.copy_(theta)                              # the views in self.p_old stay valid
+    @staticmethod
+    def _bucket_is_grad(sg: _Segment) -> bool:
+        """Are the parameters' .grad tensors the views of the network's last gradient bucket (the plain zero_grad ->
+        backward -> step loop)?  Otherwise (gradient accumulation over several backwards) .grad is gathered instead."""
+        flat = sg.net._last_grad_bucket
+        if flat is None:
+            return False
+        lay, _ = sg.net._bucket_layout()
+        base = flat.data_ptr()
+        for (_, p), loc in zip(sg.named, sg.net._param_names):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * lay[loc][0]:
+                return False
+        return True
 
     def update_importance(self) -> None:
         """Call after each optimizer step (parameters without a gradient contribute nothing, as in the reference)."""
-        theta = self._theta()
-        g = torch.cat([(p.grad.detach().reshape(-1).float() if p.grad is not None else torch.zeros(p.numel(), device=theta.device))
-                       for _, p in self._named])
-        has = torch.cat([torch.full((p.numel(),), p.grad is not None, dtype=torch.bool, device=theta.device)
-                         for _, p in self._named])
-        self._W.add_(torch.where(has, -g * (theta - self._p_old), torch.zeros_like(g)))
-        self._set_p_old(torch.where(has, theta, self._p_old))
+        for sg, W, p_old in zip(self._segs, self._W, self._p_old):
+            theta = sg.theta()
+            with _nvq.device_guard(theta.device):
+                if sg.net is not None and self._bucket_is_grad(sg):
+                    _nvq.si_update(theta, sg.net._last_grad_bucket, p_old, W)
+                    continue
+                views_w, views_p = sg.views(W), sg.views(p_old)
+                for n, p in sg.named:                         # loose parameters / accumulated gradients: per tensor
+                    if p.grad is not None:
+                        g = p.grad.detach().float().contiguous()
+                        _nvq.si_update(p.detach().float().contiguous(), g, views_p[n].view(-1), views_w[n].view(-1))
 
     def register_task(self) -> None:
-        theta = self._theta()
-        delta = theta - self._p_old
-        self._omega.add_(self._W / (delta * delta + self.damping))
-        self._W.zero_()
-        self._set_p_old(theta)
+        for sg, W, p_old, omega in zip(self._segs, self._W, self._p_old, self._omega):
+            theta = sg.theta()
+            with _nvq.device_guard(theta.device):
+                _nvq.si_consolidate(theta, float(self.damping), p_old, W, omega)
 
     def penalty(self) -> torch.Tensor:
-        return _PenaltyFn.apply(None, 2.0 * self.si_lambda, self._p_old, self._omega, *[p for _, p in self._named])
+        total = None
+        for sg, p_old, omega in zip(self._segs, self._p_old, self._omega):
+            term = _PenaltyFn.apply(sg, 2.0 * self.si_lambda, p_old, omega, *[p for _, p in sg.named])
+            total = term if total is None else total + term
+        return total

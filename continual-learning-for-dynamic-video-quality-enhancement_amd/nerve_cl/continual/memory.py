@@ -8,9 +8,25 @@ from __future__ import annotations
 
 import random
 from collections import defaultdict
+from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
 import torch
+
+
+@dataclass
+class MemorySample:
+    """One stored sample as the reference exposes it (memory.py:16-34: ``memory.buffer`` is a list of these).  The store
+    below keeps plain dicts; ``EpisodicMemory.buffer`` hands them out in this form."""
+    frame_lr: torch.Tensor
+    frame_hr: torch.Tensor
+    metadata: Dict[str, Any] = field(default_factory=dict)
+    importance: float = 1.0
+    access_count: int = 0
+
+    def to(self, device: torch.device) -> "MemorySample":
+        return MemorySample(self.frame_lr.to(device), self.frame_hr.to(device), self.metadata, self.importance,
+                            self.access_count)
 
 
 class EpisodicMemory:
@@ -38,6 +54,11 @@ class EpisodicMemory:
     def total_seen(self) -> int:
         return self._seen
 
+    @property
+    def buffer(self) -> List[MemorySample]:
+        """The stored samples in the reference's form (a read-only snapshot: tensors are shared, the list is new)."""
+        return [MemorySample(it["lr"], it["hr"], it["meta"], it["importance"], it["access_count"]) for it in self._items]
+
     @staticmethod
     def _ctype(item: dict) -> str:
         return item["meta"].get("content_type", "unknown")
@@ -55,9 +76,10 @@ class EpisodicMemory:
             return True
         return False
 
-    def store(self, lr: torch.Tensor, hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
+    def store(self, frame_lr: torch.Tensor, frame_hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
               importance: float = 1.0) -> bool:
-        item = {"lr": lr.detach().cpu(), "hr": hr.detach().cpu(), "meta": metadata or {},
+        """Reference memory.py:84-130 (same argument names: the scripts pass them positionally, callers may use keywords)."""
+        item = {"lr": frame_lr.detach().cpu(), "hr": frame_hr.detach().cpu(), "meta": metadata or {},
                 "importance": float(importance), "access_count": 0}
         self._seen += 1
         if len(self._items) < self.capacity:
@@ -139,7 +161,6 @@ class EpisodicMemory:
         self._seen = blob["total_seen"]
 
 
-
 class StreamingEpisodicMemory(EpisodicMemory):
     """Reservoir memory with a recency-biased sampler (reference memory.py:352-440): sampling weight of an item =
     (1 - recency_weight) * importance + recency_weight / (1 + now - time stored)."""
@@ -149,12 +170,12 @@ class StreamingEpisodicMemory(EpisodicMemory):
         self.recency_weight, self.compress_old = recency_weight, compress_old
         self.current_time = 0
 
-    def store(self, lr: torch.Tensor, hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
+    def store(self, frame_lr: torch.Tensor, frame_hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
               importance: float = 1.0) -> bool:
         self.current_time += 1
         meta = dict(metadata or {})
         meta["_time"] = self.current_time
-        return super().store(lr, hr, meta, importance)
+        return super().store(frame_lr, frame_hr, meta, importance)
 
     def sample(self, batch_size: int = 32, content_type: Optional[str] = None, device: Optional[torch.device] = None,
                use_recency: bool = True):

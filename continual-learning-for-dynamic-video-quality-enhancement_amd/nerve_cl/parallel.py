@@ -34,9 +34,22 @@ def init_from_env(backend: Optional[str] = None) -> "tuple[int, int, int]":
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            # RCCL: one device per rank, bound BEFORE the first allocation; the communicator is created lazily on the
+            # current device by the first collective (barrier() names the device explicitly)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def barrier(group=None) -> None:
+    """dist.barrier(); under RCCL with this rank's own device named (otherwise the barrier picks `rank % device_count`
+    and warns, and a rank that has not bound its device would create a context on GPU 0)."""
+    if world_size(group) <= 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier(group=group)
 
 
 def world_size(group=None) -> int:
@@ -62,8 +75,18 @@ def broadcast_state_(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every replica identical to rank `src` (parameters and buffers)."""
     if world_size(group) <= 1:
         return
+    # one collective per (dtype, device) instead of one per tensor (140 for the SR net): parameters and floating-point
+    # buffers travel as one flat fp32 tensor, the BatchNorm step counters as one int64 tensor
+    groups: Dict[tuple, list] = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        groups.setdefault((t.dtype, t.device), []).append(t.data)
+    for tensors in groups.values():
+        if len(tensors) == 1:
+            dist.broadcast(tensors[0], src=src, group=group)
+            continue
+        flat = flatten(tensors)
+        dist.broadcast(flat, src=src, group=group)
+        unflatten_into_(flat, tensors)
 
 
 def flatten(tensors: Iterable[torch.Tensor]) -> torch.Tensor:

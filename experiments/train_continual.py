@@ -61,6 +61,8 @@ def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
                 loss.backward()
                 optimizer.step()
                 total += loss.item()
+            if world > 1:                          # the printed loss is the mean over all ranks' batches (rank-uniform call)
+                total = parallel.allreduce_scalars([total], device=device)[0] / world
             say(f"  Epoch {epoch + 1}: Loss={total / len(loader):.4f}")
         ewc.register_task(task_id, loader)
         say(f"  Registered task {task_id} for EWC protection")

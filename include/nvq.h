@@ -107,6 +107,10 @@ typedef struct nvq_conv_desc {
      * pixel row a layer writes shares its 128-byte line with the next pixel, not with another layer.  0 = the usual
      * interleaved buffer.  Outputs, residuals and masks are ordinary (ld, coff) slices of those tensors in either case. */
     unsigned in_plane;
+    /* Kernel-variant hint, results do not depend on it: 0 = automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their
+     * 8x32-pixel, four-wave form (the automatic choice for bf16 input is the eight-wave form: 16x32 tiles for cout <= 32,
+     * two 32-channel halves per workgroup for cout >= 64).  Lets a caller A/B the two forms without any library state. */
+    int tile_rows;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */
@@ -117,12 +121,8 @@ int nvq_conv_forward(const nvq_conv_desc* d, void* stream);
  * dl's alpha / res / out2 / output).  Same results as nvq_conv_forward(d3) followed by nvq_conv_forward(dl); the concat
  * buffer is read once instead of twice.  NVQ_MATH_BF16 only. */
 int nvq_rdb_tail_forward(const nvq_conv_desc* d3, const nvq_conv_desc* dl, void* stream);
-/* Diagnostics only (tools/kernel_phases.py): 0 = normal; 1 = bf16 conv kernels skip the MFMA section;
- * 2 = they skip the per-chunk global loads after the first chunk (results are wrong in modes 1 and 2);
- * +4 = the cout <= 32 3x3 kernel uses its 8x32-pixel tiles instead of 16x32 (results unchanged). */
-int nvq_debug_set_conv_mode(int mode);
-/* diagnostics: resident workgroups per CU of conv<2,3,8>, conv<2,3,8,split>, conv<4,3,4>, rdb_tail, wgrad<3,64>, conv<2,3,4> */
-int nvq_debug_conv_occupancy(int* out6);
+/* (The library keeps no mutable state: the diagnostic switches of tools/ - nvq_debug_* - exist only in the separate
+ * libnvq_debug.so that `NVQ_DEBUG_TOOLS=1 build.sh` makes; tools/nvq_debug.h declares them.) */
 size_t nvq_sizeof_conv_desc(void);
 
 /* Combined weights for the backward of one ResidualDenseBlock (super_resolution.py:245-253) in "mirror"
@@ -478,6 +478,12 @@ int nvq_ewc_penalty_grad(const float* theta, const float* theta_star, const floa
                          int accumulate, void* stream);
 /* EWC.compute_fisher accumulation, ewc.py:139-141: fisher += grad^2 */
 int nvq_fisher_accumulate(const float* grad, long n, float* fisher, void* stream);
+/* SynapticIntelligence on flat buckets (theta, grad, p_old, W, omega in one layout, n floats each).
+ * update_importance, ewc.py:343-354:  W += -grad * (theta - p_old);  p_old = theta.
+ * register_task, ewc.py:356-368:      omega += W / ((theta - p_old)^2 + damping);  W = 0;  p_old = theta.
+ * (The penalty si_lambda * sum omega (theta - p_old)^2, ewc.py:370-379, is nvq_ewc_penalty with lambda = 2 si_lambda.) */
+int nvq_si_update(const float* theta, const float* grad, long n, float* p_old, float* W, void* stream);
+int nvq_si_consolidate(const float* theta, long n, float damping, float* p_old, float* W, float* omega, void* stream);
 
 #ifdef __cplusplus
 }

@@ -340,6 +340,175 @@ def run_fr(name, cfg):
           f"{sum(p.numel() for p in ref.parameters())} parameters")
 
 
+from oracle import cl_cases  # noqa: E402
+META = cl_cases.META
+
+
+class Adapter4D(torch.nn.Module):
+    """4-D frames -> the SR net's 5-D clip (T identical frames), tensor out: SURVEY.md 3.4's adapter around the reference's
+    own `lr.unsqueeze(1).expand(-1, 3, ...)` (train_continual.py:51)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, x):
+        return self.net(x.unsqueeze(1).expand(-1, 3, -1, -1, -1))
+
+
+def delta_summaries(before, after):
+    """per-parameter [sum, l2, 16 samples] of (after - before), float64"""
+    return {n: grad_summary(after[n].detach().double() - before[n].detach().double()) for n in before}
+
+
+def _close_summ(a, b, what, tol=2e-3):
+    """two summary vectors agree relative to the l2 entry (parameter updates are lr * gradient: their fp32 error is an ulp of
+    the PARAMETER, so compare at the update's own scale with a tolerance above that)"""
+    scale = max(abs(b[1]), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= tol, f"{what}: {err:.3e}"
+    return err
+
+
+def run_meta(RefSR):
+    """reference FOMAML.adapt (maml.py:168-186 -> :74-110) and Reptile.train_step (:276-345) on the
+    reference SR net; stored: per-parameter summaries of the parameter CHANGE, losses, BatchNorm buffers."""
+    from nerve_cl.continual import FOMAML as RefFOMAML, Reptile as RefReptile
+    from oracle import cl_oracle
+    c = META
+    sd = synth.formula_state(3, c["s"], c["F"], c["N"], c["win"], gain=GAIN)
+
+    data = cl_cases.clip_pair
+
+    def make_ref():
+        m = RefSR(3, c["s"], c["F"], c["N"], c["win"])
+        m.load_state_dict(sd)
+        return m.train()
+
+    def make_ora():
+        m = sr_oracle.OracleSR(3, c["s"], c["F"], c["N"], c["win"])
+        m.load_named(sd)
+        return m.train()
+
+    blob = {"cfg": np.array([c["F"], c["N"], c["win"], c["s"], 2, c["H"], c["W"]]),
+            "fomaml_inner_lr": np.array(0.05), "fomaml_steps": np.array(3),
+            "reptile_inner_lr": np.array(0.05), "reptile_outer_lr": np.array(0.5), "reptile_inner_steps": np.array(2)}
+    # --- FOMAML.adapt, 3 inner steps
+    ref = make_ref()
+    before = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    adapted = RefFOMAML(ref, inner_lr=0.05, inner_steps=3).adapt(data(61), F.mse_loss)
+    assert all(torch.equal(p, before[n]) for n, p in ref.named_parameters())      # the meta-model itself is untouched
+    ora = make_ora()
+    o_adapted = cl_oracle.fomaml_adapt(ora, data(61), F.mse_loss, 0.05, 3)
+    ref_d = delta_summaries(before, dict(adapted.named_parameters()))
+    ora_d = delta_summaries({n: ora.named()[n] for n in before}, {n: o_adapted.named()[n] for n in before})
+    worst = max(_close_summ(ora_d[n], ref_d[n], "fomaml " + n) for n in ref_d)
+    adapted.eval()
+    with torch.no_grad():
+        x, t = data(61)
+        blob["fomaml_eval_loss"] = np.array(F.mse_loss(adapted(x), t).item(), dtype=np.float64)
+    for n, v in ref_d.items():
+        blob["fomaml_delta/" + n] = v
+    for n in sr_oracle.buffer_shapes(c["F"]):
+        blob["fomaml_buf/" + n] = adapted.state_dict()[n].numpy()
+    # --- Reptile.train_step, 2 tasks x 2 inner steps
+    ref = make_ref()
+    before = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    tasks = [{"support": data(71)}, {"support": data(72)}]
+    rl = RefReptile(ref, inner_lr=0.05, outer_lr=0.5, inner_steps=2).train_step(tasks, F.mse_loss)
+    ora = make_ora()
+    o_before = {n: ora.named()[n].detach().clone() for n in before}
+    ol = cl_oracle.reptile_train_step(ora, tasks, F.mse_loss, 0.05, 0.5, 2)
+    assert abs(rl - ol) <= 1e-5 * abs(rl), (rl, ol)
+    ref_d = delta_summaries(before, dict(ref.named_parameters()))
+    ora_d = delta_summaries(o_before, {n: ora.named()[n] for n in before})
+    worst = max(worst, max(_close_summ(ora_d[n], ref_d[n], "reptile " + n) for n in ref_d))
+    blob["reptile_loss"] = np.array(rl, dtype=np.float64)
+    for n, v in ref_d.items():
+        blob["reptile_delta/" + n] = v
+    for n in sr_oracle.buffer_shapes(c["F"]):
+        blob["reptile_buf/" + n] = ref.state_dict()[n].numpy()
+    np.savez_compressed(os.path.join(OUT, "meta_f16.npz"), **blob)
+    print(f"meta: fomaml eval loss {blob['fomaml_eval_loss']:.6f}, reptile loss {rl:.6f}, oracle-vs-ref worst {worst:.2e}")
+
+
+def run_si(RefSR):
+    """Reference SynapticIntelligence (ewc.py:306-379) around the reference SR net: 3 SGD steps with update_importance,
+    register_task, then 2 steps of `mse + penalty` with update_importance after each (penalty stays 0: a reference quirk, see below) and 2
+    without it (non-zero penalty)."""
+    from nerve_cl.continual import SynapticIntelligence as RefSI
+    from oracle import cl_oracle
+    c = META
+    sd = synth.formula_state(3, c["s"], c["F"], c["N"], c["win"], gain=GAIN)
+    x, t = cl_cases.si_pair()
+
+    drive = lambda model, si, named: cl_cases.si_drive(model, si, named, x, t)  # noqa: E731
+
+    ref = RefSR(3, c["s"], c["F"], c["N"], c["win"])
+    ref.load_state_dict(sd)
+    names = [n for n, _ in ref.named_parameters()]
+    rW, rO, rp, rl = drive(ref, RefSI(ref, si_lambda=2000.0, damping=0.1), names)
+    ora = sr_oracle.OracleSR(3, c["s"], c["F"], c["N"], c["win"])
+    ora.load_named(sd)
+    osi = cl_oracle.SI(ora, si_lambda=2000.0, damping=0.1)
+    key = {n: n.replace(".", "|") for n in names}
+    oW, oO, op, ol = drive(ora, osi, [key[n] for n in names])
+    assert np.allclose(rl, ol, rtol=1e-5), (rl, ol)
+    assert np.allclose(rp, op, rtol=2e-3), (rp, op)
+    worst = 0.0
+    for n in names:
+        worst = max(worst, _close_summ(grad_summary(oW[key[n]]), grad_summary(rW[n]), "si W " + n, 5e-3))
+        worst = max(worst, _close_summ(grad_summary(oO[key[n]]), grad_summary(rO[n]), "si omega " + n, 5e-3))
+    blob = {"cfg": np.array([c["F"], c["N"], c["win"], c["s"], 2, c["H"], c["W"]]), "si_lambda": np.array(2000.0),
+            "damping": np.array(0.1), "lr": np.array(0.05), "penalties": np.array(rp), "losses": np.array(rl)}
+    for n in names:
+        blob["W/" + n] = grad_summary(rW[n])
+        blob["omega/" + n] = grad_summary(rO[n])
+    np.savez_compressed(os.path.join(OUT, "si_f16.npz"), **blob)
+    print("si: penalties", rp, "losses", rl, f"oracle-vs-ref worst {worst:.2e}")
+
+
+def run_cfg5_loop(RefSR, RefEWC):
+    """the loop of experiments/train_continual.py:26-69 (`train_with_ewc`) driven with the reference EWC and
+    the reference SR net through the 4-D -> 5-D adapter: 2 tasks (create_task_data-style offsets +0.2 / -0.2 on formula
+    data) x 1 epoch of 3 batches of 2, Adam(1e-4), loss = mse + penalty, lambda 5000, register_task after each task on the
+    same batches.  Stored: per-step task_loss / ewc_loss, final Fisher summaries."""
+    from oracle import cl_oracle
+    c = META
+    sd = synth.formula_state(3, c["s"], c["F"], c["N"], c["win"], gain=GAIN)
+    tasks = cl_cases.cfg5_tasks()
+
+    ref = Adapter4D(RefSR(3, c["s"], c["F"], c["N"], c["win"]))
+    ref.net.load_state_dict(sd)
+    ewc = RefEWC(ref, ewc_lambda=5000.0)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    crit = torch.nn.MSELoss()
+    tl, el = [], []
+    for task_id, (_, batches) in enumerate(tasks):
+        ref.train()
+        for lr_b, hr_b in batches:
+            opt.zero_grad()
+            task_loss = crit(ref(lr_b), hr_b)
+            ewc_loss = ewc.penalty()
+            (task_loss + ewc_loss).backward()
+            opt.step()
+            tl.append(task_loss.item())
+            el.append(float(ewc_loss.item()) if torch.is_tensor(ewc_loss) else float(ewc_loss))
+        ewc.register_task(task_id, batches)
+
+    ora = Adapter4D(sr_oracle.OracleSR(3, c["s"], c["F"], c["N"], c["win"]))
+    ora.net.load_named(sd)
+    log = cl_oracle.train_with_ewc(ora, tasks, 5000.0, 1e-4, 1)
+    assert np.allclose(tl, log["task_loss"], rtol=1e-5), (tl, log["task_loss"])
+    assert np.allclose(el, log["ewc_loss"], rtol=2e-3, atol=1e-12), (el, log["ewc_loss"])
+    blob = {"cfg": np.array([c["F"], c["N"], c["win"], c["s"], 2, c["H"], c["W"]]), "task_loss": np.array(tl),
+            "ewc_loss": np.array(el), "offsets": np.array([0.2, -0.2]), "lr": np.array(1e-4), "ewc_lambda": np.array(5000.0)}
+    for n, f in ewc.fisher_dict.items():
+        blob["fisher/" + n[len("net."):]] = grad_summary(f)
+    np.savez_compressed(os.path.join(OUT, "cfg5_loop.npz"), **blob)
+    print("cfg5 loop: task_loss", tl, "ewc_loss", el)
+
+
 FR_CASES = {"fr_b16_train": (16, 2, 2, 32, 48, True), "fr_b16_eval": (16, 1, 2, 40, 40, False)}
 
 
@@ -350,6 +519,11 @@ def main():
     RefSR, RefEWC = import_reference()
     if "--only-fr-init" in sys.argv:
         run_default_init_fr()
+        return
+    if "--only-cl" in sys.argv:
+        run_meta(RefSR)
+        run_si(RefSR)
+        run_cfg5_loop(RefSR, RefEWC)
         return
     if "--only-fr" in sys.argv:
         for name, cfg in FR_CASES.items():
@@ -363,6 +537,9 @@ def main():
         run_case(name, cfg, RefSR)
     run_trajectory(RefSR)
     run_ewc(RefSR, RefEWC)
+    run_meta(RefSR)
+    run_si(RefSR)
+    run_cfg5_loop(RefSR, RefEWC)
     run_default_init(RefSR)
     for name, cfg in FR_CASES.items():
         run_fr(name, cfg)

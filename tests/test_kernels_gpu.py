@@ -867,8 +867,8 @@ def test_conv_bf16_tall_tiles_mask_and_bias(K, cin, N, H, W):
                                                    (96, 128, 0, False, 24, 33), (64, 81, 0, False, 17, 50)])
 def test_conv_bf16_eight_wave_kernels_equal_the_four_wave_ones(K, cin, cout, ctr, res, H, W):
     """The two 8-wave 3x3 kernels the benchmark runs - 16x32 tiles for cout <= 32, and the channel-split one (two halves of the
-    workgroup = 32 output channels each) for cout 64 / 128 - against the single-tile 4-wave kernels they replaced (diagnostic
-    mode 4 of nvq_debug_set_conv_mode selects those): the same sums in the same order, bit-identical, with bias / residual /
+    workgroup = 32 output channels each) for cout 64 / 128 - against the single-tile 4-wave kernels they replaced
+    (nvq_conv_desc::tile_rows = 8 selects those): the same sums in the same order, bit-identical, with bias / residual /
     centre-tap chunks / a second 64-channel slab (cout 128, 81)."""
     N = 2
     w = rnd(cout, cin, 3, 3, scale=0.1)
@@ -883,15 +883,11 @@ def test_conv_bf16_eight_wave_kernels_equal_the_four_wave_ones(K, cin, cout, ctr
     r16 = to_nhwc_bf16(bf(rnd(N, 64, H, W, seed=7)), 64) if res else None
     cs = (cout + 7) // 8 * 8
     outs = []
-    try:
-        for mode in (0, 4):
-            K.lib().nvq_debug_set_conv_mode(mode)
-            out = torch.full((N, H, W, cs), 3.0, device="cuda").bfloat16()
-            K.conv_forward(K.Sl(xin, cin, 0), wp, bias, K.Sl(out, cout), 3, cout_store=cs, math=K.MATH_BF16, center_cin=ctr,
-                           res=K.Sl(r16) if res else None)
-            outs.append(out)
-    finally:
-        K.lib().nvq_debug_set_conv_mode(0)
+    for rows in (0, 8):
+        out = torch.full((N, H, W, cs), 3.0, device="cuda").bfloat16()
+        K.conv_forward(K.Sl(xin, cin, 0), wp, bias, K.Sl(out, cout), 3, cout_store=cs, math=K.MATH_BF16, center_cin=ctr,
+                       res=K.Sl(r16) if res else None, tile_rows=rows)
+        outs.append(out)
     assert torch.equal(outs[0], outs[1])
     ref = F.conv2d(x, bf(w), bias.cpu() if bias is not None else None, padding=1)
     if res:

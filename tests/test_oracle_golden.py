@@ -175,3 +175,88 @@ def test_frame_recovery_oracle_matches_reference_fixture(path):
         elif key.startswith("buf/"):
             assert _rel(P[key[4:]].double().numpy(), g[key]) < 1e-5, key
     assert seen == len(shapes)
+
+
+# ---------------------------------------------------------------- continual-learning consumers
+def _summ_close(got, ref, what, tol):
+    """summary vectors [sum, l2, 16 samples] at the scale of the tensor's own l2"""
+    err = np.abs(np.asarray(got) - np.asarray(ref)).max() / max(abs(ref[1]), 1e-30)
+    assert err <= tol, f"{what}: {err:.3e}"
+
+
+def _oracle_net():
+    from oracle import cl_cases
+    c = cl_cases.META
+    m = sr_oracle.OracleSR(3, c["s"], c["F"], c["N"], c["win"])
+    m.load_named(cl_cases.state())
+    return m.train()
+
+
+def test_meta_learning_oracle_matches_reference_fixture(golden_dir):
+    """oracle/cl_oracle.py's FOMAML.adapt / Reptile.train_step restatements against the parameter changes the reference's
+    own classes produced (tests/golden/meta_f16.npz)."""
+    from oracle import cl_cases, cl_oracle
+    from oracle.make_goldens import delta_summaries
+    g = np.load(os.path.join(golden_dir, "meta_f16.npz"))
+    fo, rp = cl_cases.FOMAML, cl_cases.REPTILE
+    m = _oracle_net()
+    names = [k[len("fomaml_delta/"):] for k in g.files if k.startswith("fomaml_delta/")]
+    assert len(names) == 47
+    before = {n: m.named()[n].detach().clone() for n in names}
+    ad = cl_oracle.fomaml_adapt(m, cl_cases.clip_pair(fo["data_seed"]), F.mse_loss, fo["inner_lr"], fo["steps"])
+    assert all(torch.equal(m.named()[n], before[n]) for n in names)
+    d = delta_summaries(before, {n: ad.named()[n] for n in names})
+    for n in names:
+        _summ_close(d[n], g["fomaml_delta/" + n], "fomaml " + n, 2e-3)
+    ad.eval()
+    with torch.no_grad():
+        x, t = cl_cases.clip_pair(fo["data_seed"])
+        assert abs(F.mse_loss(ad(x), t).item() - float(g["fomaml_eval_loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("fomaml_buf/"):
+            assert _rel(ad.named()[k[len("fomaml_buf/"):]].double().numpy(), g[k]) < 1e-5, k
+
+    m = _oracle_net()
+    before = {n: m.named()[n].detach().clone() for n in names}
+    tasks = [{"support": cl_cases.clip_pair(s)} for s in rp["data_seeds"]]
+    loss = cl_oracle.reptile_train_step(m, tasks, F.mse_loss, rp["inner_lr"], rp["outer_lr"], rp["inner_steps"])
+    assert abs(loss - float(g["reptile_loss"])) < 1e-6
+    d = delta_summaries(before, {n: m.named()[n] for n in names})
+    for n in names:
+        _summ_close(d[n], g["reptile_delta/" + n], "reptile " + n, 2e-3)
+    for k in g.files:
+        if k.startswith("reptile_buf/"):
+            assert _rel(m.named()[k[len("reptile_buf/"):]].double().numpy(), g[k]) < 1e-5, k
+
+
+def test_synaptic_intelligence_oracle_matches_reference_fixture(golden_dir):
+    from oracle import cl_cases, cl_oracle
+    g = np.load(os.path.join(golden_dir, "si_f16.npz"))
+    m = _oracle_net()
+    si = cl_oracle.SI(m, cl_cases.SI["si_lambda"], cl_cases.SI["damping"])
+    names = [k[2:] for k in g.files if k.startswith("W/")]
+    key = {n: n.replace(".", "|") for n in names}
+    x, t = cl_cases.si_pair()
+    W, omega, pens, losses = cl_cases.si_drive(m, si, [key[n] for n in names], x, t)
+    assert np.allclose(losses, g["losses"], rtol=1e-5)
+    assert pens[:3] == [0.0, 0.0, 0.0] and list(g["penalties"][:3]) == [0.0, 0.0, 0.0]     # the p_old quirk (cl_cases.si_drive)
+    assert np.allclose(pens[3:], g["penalties"][3:], rtol=2e-3) and g["penalties"][4] > 1e-4
+    for n in names:
+        _summ_close(grad_summary(W[key[n]]), g["W/" + n], "W " + n, 5e-3)
+        _summ_close(grad_summary(omega[key[n]]), g["omega/" + n], "omega " + n, 5e-3)
+
+
+def test_train_with_ewc_loop_oracle_matches_reference_fixture(golden_dir):
+    """The `mse + penalty` optimisation trajectory of experiments/train_continual.py:26-69: per-step
+    task_loss / ewc_loss captured from reference EWC + reference SR net through the 4-D -> 5-D adapter."""
+    from oracle import cl_cases, cl_oracle
+    from oracle.make_goldens import Adapter4D
+    g = np.load(os.path.join(golden_dir, "cfg5_loop.npz"))
+    m = Adapter4D(_oracle_net())
+    log = cl_oracle.train_with_ewc(m, cl_cases.cfg5_tasks(), cl_cases.CFG5["lam"], cl_cases.CFG5["lr"], 1)
+    assert np.allclose(log["task_loss"], g["task_loss"], rtol=1e-5)
+    assert list(g["ewc_loss"][:4]) == [0.0] * 4 and log["ewc_loss"][:4] == [0.0] * 4
+    assert np.allclose(log["ewc_loss"][4:], g["ewc_loss"][4:], rtol=2e-3) and g["ewc_loss"][5] > 1e-6
+    for k in g.files:
+        if k.startswith("fisher/"):
+            _summ_close(grad_summary(log["fisher"]["net." + k[7:].replace(".", "|")]), g[k], k, 1e-3)
