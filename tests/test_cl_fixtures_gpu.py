@@ -98,8 +98,17 @@ def test_synaptic_intelligence_on_the_flat_bucket_matches_the_reference(golden_d
     for n in names:
         _summ_close(grad_summary(W[n].cpu()), g["W/" + n], "W " + n, 1e-2)
         _summ_close(grad_summary(omega[n].cpu()), g["omega/" + n], "omega " + n, 1e-2)
-    # the one-launch path was the one that ran: the .grad tensors are the views of the network's gradient bucket
+    # after a plain zero_grad -> backward -> step the .grad tensors ARE the views of the network's gradient bucket, i.e.
+    # update_importance is the one-launch path (a backward that also accumulated a separately returned penalty gradient,
+    # like the last steps of si_drive, replaces .grad by a sum and takes the per-tensor path)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01)
+    opt.zero_grad()
+    _mse()(net(x), t).backward()
+    opt.step()
     assert si._bucket_is_grad(si._segs[0])
+    w0 = si._W[0].clone()
+    si.update_importance()
+    assert not torch.equal(w0, si._W[0]) and torch.equal(si._p_old[0], net.flat_theta())
 
 
 def test_train_with_ewc_loop_matches_the_reference_trajectory(golden_dir):
