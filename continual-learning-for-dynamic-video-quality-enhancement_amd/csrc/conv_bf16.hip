@@ -10,7 +10,6 @@
 //   * nothing between the prefetch and the next commit may USE a loaded value (not even a select);
 //   * register pieces are ext_vector types: HIP's uint4 struct is not scalar-replaced and lands in scratch;
 //   * the packed weight slab is padded to a whole number of 16-byte pieces per thread.
-#include <stdlib.h>
 #include "conv_common.h"
 
 namespace nvq {
@@ -870,7 +869,6 @@ void conv_occupancy_bf16(int* out) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[3], rdb_tail_kernel, 256, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[4], wgrad_bf16_kernel<3, true, true, 64, 32>, 256, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[5], conv_bf16_kernel<2, 3, true, 4>, 256, 0);
-    out[6] = wgrad_strip_occupancy();
 }
 
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {
@@ -886,15 +884,6 @@ int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int t
                     hipStream_t s) {
     // nsplit / nci come from the caller in 32-ci units; with bf16 x and >= 64 input channels use 64-ci workgroups
     const bool wide = d.x_bf16 && d.dy_bf16 && d.cin_w >= 64;   // (the bf16-x / fp32-dy wide variant spills)
-    // 3x3 with 65 .. 96 input channels (the dense layer cin = 96, the flow net's 81 -> 128): ONE 96-channel workgroup per
-    // tile instead of a full and a half-empty 64-channel one (wgrad_strip.hip; measured 1.10x / 1.26x on those two shapes,
-    // slower than this kernel on every other one - DESIGN.md section 5).  NVQ_WGRAD_STRIP=1 / 0 forces it on / off for
-    // every cin >= 64 shape (tests, tools/wgrad_shapes.py).
-    if (wide && d.ksize == 3) {
-        const char* force = getenv("NVQ_WGRAD_STRIP");
-        const bool strip = force ? force[0] == '1' : nci == 3;
-        if (strip) return conv_wgrad_strip_bf16(d, nci, nco, s);
-    }
     const int ncig = wide ? (nci + 1) / 2 : nci;
     if (wide) {
         nsplit = WGRAD_MAX_WG / (ncig * nco);

@@ -8,7 +8,7 @@ constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
 constexpr int WGRAD_MAX_WG = 512;      // workgroups per wgrad launch (2 per CU)
-constexpr int WGRAD_MAX_SLABS = 2048;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds
+constexpr int WGRAD_MAX_SLABS = 1024;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds
 
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
@@ -31,8 +31,6 @@ PackJobDev pack_job_bf16(const nvq_pack_job& j);
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s);
-int wgrad_strip_occupancy();
-int conv_wgrad_strip_bf16(const nvq_wgrad_desc& d, int nci32, int nco, hipStream_t s);
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s);
 
 // Bias-gradient partials of the wgrad kernels: every thread holds the column sums of the dy pieces it staged

@@ -8,8 +8,8 @@ extern "C" {
 /* 0 = normal; 1 = the bf16 conv kernels skip the MFMA section; 2 = they skip the per-chunk global loads after the first
  * chunk.  Results are wrong in modes 1 and 2.  Process-wide. */
 int nvq_debug_set_conv_mode(int mode);
-/* resident workgroups per CU of conv<2,3,8>, conv<2,3,8,split>, conv<4,3,4>, rdb_tail, wgrad<3,64>, conv<2,3,4>, wgrad_strip */
-int nvq_debug_conv_occupancy(int* out8);
+/* resident workgroups per CU of conv<2,3,8>, conv<2,3,8,split>, conv<4,3,4>, rdb_tail, wgrad<3,64>, conv<2,3,4> */
+int nvq_debug_conv_occupancy(int* out6);
 #ifdef __cplusplus
 }
 #endif
