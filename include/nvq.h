@@ -109,7 +109,8 @@ typedef struct nvq_conv_desc {
     unsigned in_plane;
     /* Kernel-variant hint, results do not depend on it: 0 = automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their
      * 8x32-pixel, four-wave form (the automatic choice for bf16 input is the eight-wave form: 16x32 tiles for cout <= 32,
-     * two 32-channel halves per workgroup for cout >= 64).  Lets a caller A/B the two forms without any library state. */
+     * two 32-channel halves per workgroup for cout >= 64); 16 = the eight-wave form with one tile per workgroup also where the
+     * library would run its persistent dense-layer kernel.  Lets a caller A/B the forms without any library state. */
     int tile_rows;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
