@@ -95,9 +95,36 @@ __global__ void pack_batch_bf16_kernel(const PackJobTable t) {
 // CS = 2 (NW = 8): the workgroup's waves split in two halves that compute output channels [0, NT) and [NT, 2 NT) of the SAME
 // 8 x 32 pixel tile (a 64-channel 3x3 conv at the register budget and the four waves per SIMD of the 32-channel kernel: with
 // all 64 channels in one wave the accumulators and the 37 KB weight slab's prefetch registers leave two waves per SIMD).
-template <int NB, int KS, bool INB, int NW = 4, int CS = 1>
+// TS > 0: the upsampler tail (PixelShuffleUpsampler.conv efficient_layers.py:94-100 + PixelShuffle(TS) :101-106 + the bicubic
+// skip and the clamp of super_resolution.py:378-382) as this kernel's epilogue: the tile's 3 TS^2 conv outputs go through LDS,
+// are read back as TS x TS pixel blocks, and the frame is written (no intermediate tensor); `tail` says where.
+struct TailArgs {
+    const float* frames;   // fp32 NCHW clip (B, T, Cimg, H, W)
+    float* out;            // fp32 NCHW (B, Cimg, H*TS, W*TS)
+    unsigned char* pass;   // 1 where 0 <= pre-clamp <= 1
+    int T, t_center, Cimg;
+};
+// Keys cubic convolution, A = -0.75 (PyTorch upsample_bicubic2d, align_corners=False); the same arithmetic as
+// shuffle_bicubic_clamp_kernel (upsample.hip)
+__device__ __forceinline__ float tcc1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float tcc2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ void tail_cubic_taps(int dst, float scale, int size, int idx[4], float w[4]) {
+    const float real = scale * ((float)dst + 0.5f) - 0.5f;
+    const float fl = floorf(real);
+    const float t = real - fl;
+    const int i0 = (int)fl;
+    w[0] = tcc2(t + 1.f);
+    w[1] = tcc1(t);
+    w[2] = tcc1(1.f - t);
+    w[3] = tcc2((1.f - t) + 1.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(i0 - 1 + k, 0), size - 1);
+}
+
+template <int NB, int KS, bool INB, int NW = 4, int CS = 1, int TS = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(const nvq_conv_desc d, int tilesX,
-                                                                               int tilesY, int nkc, int vec_ok, int dbg) {
+                                                                               int tilesY, int nkc, int vec_ok, int dbg,
+                                                                               const TailArgs tail) {
     constexpr int NT = NB * 16;                               // output channels of one wave
     constexpr int NTW = NT * CS;                              // ... of the workgroup (= the packed slab's width)
     constexpr int NTHR = 64 * NW;
@@ -272,6 +299,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
     };
 
+    // CS = 2: a half whose 32 channels lie beyond the stored ones (cout_store = 96: the second half of the second slab of the
+    // flow net's 128 -> 81 input gradient) stages with the others but leaves the matrix cores to the other waves
+    const bool dead = CS == 2 && cz * NT >= d.cout_store;     // (wave-uniform)
     int kc = 0;
     // Leading chunks whose weights are zero outside the centre tap (nvq_conv_desc::center_cin): one stage instead of nine.
     // Loops of their own - as a branch inside the main loop the same code cost the main path 60 VGPRs.
@@ -280,10 +310,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             fetch(0, true);
             for (; kc + 1 < kcl; ++kc) {
                 stage_chunk(kc, true, true);
-                if (!(dbg & 1)) center_stage();
+                if (!(dbg & 1) && !dead) center_stage();
             }
             stage_chunk(kc, true, false);                    // the last of them fetches a full slab
-            if (!(dbg & 1)) center_stage();
+            if (!(dbg & 1) && !dead) center_stage();
             ++kc;
         } else {
             fetch(0, false);
@@ -293,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
     }
     for (; kc < nkc; ++kc) {
         stage_chunk(kc, false, false);
-        if (dbg & 1) continue;
+        if ((dbg & 1) || dead) continue;
         // Fragment reads software-pipelined against the MFMAs (the compiler otherwise emits read -> lgkmcnt(0) ->
         // 4 MFMAs, exposing the LDS latency 2*TAPS times per chunk).  Stages run dx-major, dy-minor: going from dy to
         // dy+1 the wave's upper output row reuses the fragments of the lower one, so a stage needs only the two
@@ -338,6 +368,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
             }
         }
     }
+    if constexpr (TS > 0) {
+        // ---- upsampler tail.  acc[cb][pb]: channels cb*16 + 4g .. +3 of pixel (row 2 wave + (pb >> 1), x = (pb & 1)*16 + c).
+        static_assert(NW == 4 && CS == 1, "8 x 32-pixel tiles");
+        constexpr int CP = NT + 1;                           // floats per pixel of the LDS tile (odd: spreads the banks)
+        static_assert(TH * TW * CP * 4 <= (NPIX * XSB + WS_HALFS) * 2, "the conv output tile fits the LDS stages");
+        float* ut = reinterpret_cast<float*>(lds);
+        const int U = tail.Cimg * TS * TS;                   // real conv channels
+        __syncthreads();                                      // every wave is done reading xs / ws
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int px = (2 * wave + (pb >> 1)) * TW + (pb & 1) * 16 + c;
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cb * 16 + 4 * g + e;
+                    if (co < U) ut[px * CP + co] = acc[cb][pb][e] + (d.bias ? d.bias[co] : 0.f);
+                }
+        }
+        __syncthreads();
+        const int OW = W * TS, OH = H * TS;
+        const float scale = 1.f / (float)TS;
+        constexpr int OWt = TW * TS, OHt = TH * TS;
+        const float* frame = tail.frames + (size_t)(n * tail.T + tail.t_center) * tail.Cimg * H * W;
+        for (int idx = tid; idx < OHt * OWt; idx += NTHR) {  // one thread per HR pixel of the tile, all image channels
+            const int oyl = idx / OWt, oxl = idx - oyl * OWt;
+            const int oy = ty * OHt + oyl, ox = tx * OWt + oxl;
+            if (oy >= OH || ox >= OW) continue;
+            const int hl = oyl / TS, i = oyl - hl * TS, wl = oxl / TS, j = oxl - wl * TS;
+            int xi[4], yi[4];
+            float wx[4], wy[4];
+            tail_cubic_taps(ox, scale, W, xi, wx);
+            tail_cubic_taps(oy, scale, H, yi, wy);
+            const float* up = ut + (hl * TW + wl) * CP + i * TS + j;
+            for (int ch = 0; ch < tail.Cimg; ++ch) {
+                const float* img = frame + (size_t)ch * H * W;
+                float bic = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float* row = img + (size_t)yi[a] * W;
+                    const float r = wx[0] * row[xi[0]] + wx[1] * row[xi[1]] + wx[2] * row[xi[2]] + wx[3] * row[xi[3]];
+                    bic += wy[a] * r;
+                }
+                const float pre = bic + up[ch * TS * TS];
+                const size_t o = ((size_t)(n * tail.Cimg + ch) * OH + oy) * OW + ox;
+                tail.pass[o] = (pre >= 0.f && pre <= 1.f) ? 1 : 0;
+                tail.out[o] = fminf(fmaxf(pre, 0.f), 1.f);
+            }
+        }
+        return;
+    }
     constexpr int SPX = NB == 2 ? STAGE_PX : STAGE_PX64;
     if constexpr (NB >= 2 && 2 * TW * SPX * NW <= NPIX * XSB + WS_HALFS) {
         // full 32 / 64-channel bf16 outputs: stage the tile's output in LDS and store whole pixel rows (64 / 128 B)
@@ -363,296 +444,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         }
     }
     conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_);
-}
-
-// ---------------------------------------------------------------- dense layers, persistent form
-// The 3x3 convs of ResidualDenseBlock (super_resolution.py:245-253: cin = F + 32 i -> 32 channels, bias + ReLU) and their
-// mirror-form gradients (nvq_rdb_backward_weights) are 73 launches of a training step and small per tile: with one tile per
-// workgroup, a third to a half of a tile's time is its fixed part - kernel entry and index arithmetic, the exposed fetch of
-// its first K chunk, the epilogue (cycle stamps).  Here a workgroup walks tiles, and the first chunk of
-// tile t + 1 is fetched into the staging registers BEFORE the epilogue of tile t, so that fetch (and the next tile's index
-// arithmetic) runs under the epilogue and the stores instead of in front of an idle matrix core.  What made this fail
-// before (round 2: the next tile's 32 prefetch registers live across the generic epilogue spilled at 128 VGPRs) is avoided
-// by compiling the epilogue for exactly the two cases the dense layers use: BM = 1: bias + ReLU, bf16 output, one-bit ReLU
-// masks written (forward); BM = 2: the mask bits read, no bias (gradient).  Same tiles (16 x 32 pixels, 8 waves), same
-// staging, same MFMA order as conv_bf16_kernel<2, 3, true, 8>: bit-identical results.
-template <int BM>
-__global__ __launch_bounds__(512, 4) void conv_dense_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int ntiles, int nkc) {
-    constexpr int NB = 2, KS = 3, NW = 8, NT = 32, NTHR = 512, TH_ = 16, TAPS = 9;
-    constexpr int HW_ = TW + 2, HH_ = TH_ + 2, NPIX = HW_ * HH_;
-    constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);
-    constexpr int XITEMS = NPIX * 4;
-    constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;          // 5
-    constexpr int WPIECES = TAPS * 4 * NT;                    // 1152
-    constexpr int WPER = (WPIECES + NTHR - 1) / NTHR;         // 3
-    constexpr int CT_K = (TAPS / 2) * 4 * NT / NTHR;          // 1: the centre tap's pieces are register 1 of threads 0..127
-    constexpr int CT_N = 4 * NT;
-    static_assert(((TAPS / 2) * 4 * NT) % NTHR == 0, "the centre tap starts a register row");
-    static_assert(2 * TW * STAGE_PX * NW <= NPIX * XSB + WS_HALFS, "the output staging tiles fit the LDS stages");
-
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS_HALFS];
-    __bf16* xs = lds;
-    __bf16* ws = lds + NPIX * XSB;
-    const int kcl = d.center_cin / KCB;                       // leading chunks that only have a centre tap
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int c = lane & 15;
-    const int g = lane >> 4;
-    const int H = d.h, W = d.w;
-
-    f32x4 acc[NB][4];
-    const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack);
-    const __bf16* in16 = reinterpret_cast<const __bf16*>(d.in) + d.in_coff;
-    const int nk0 = d.in_plane ? d.in_ld >> 5 : 0x7fffffff;   // chunks that live in the leading tensor (all, if interleaved)
-    const int sh0 = d.in_plane ? __ffs(d.in_ld >> 5) - 1 : 0; // log2(in_ld / 32)
-    const unsigned pmul = d.in_plane ? 32 : d.in_ld;
-    const int chg = 8 * (tid & 3);
-
-    unsigned xoff[XPER];
-    unsigned okm = 0;                                         // bit k: piece k lies inside the image
-    bool interior = false;
-    // element offsets / validity of the pieces of tile (n, ty, tx); out-of-image pieces point at element 0
-    // (the halo positions are recomputed from an opaque copy of the thread id: as loop invariants they would be hoisted
-    // out of the tile loop, ten registers that live through every K loop and spill)
-    auto geometry = [&](int n, int ty, int tx) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        okm = 0;
-#pragma unroll
-        for (int k = 0; k < XPER; ++k) {
-            const int hp = (tv + k * NTHR) >> 2;
-            const int hy = hp / HW_;
-            const int gy = ty * TH_ + hy - 1, gx = tx * TW + (hp - hy * HW_) - 1;
-            const bool ok = tv + k * NTHR < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            okm |= (ok ? 1u : 0u) << k;
-            xoff[k] = ok ? (unsigned)((n * H + gy) * W + gx) * pmul : 0u;
-        }
-        interior = ty * TH_ >= 1 && tx * TW >= 1 && ty * TH_ + TH_ + 1 <= H && tx * TW + TW + 1 <= W;
-    };
-    u32x4 xr[XPER];
-    u32x4 wr[WPER];
-    // raw loads only: nothing here may USE a loaded value (see conv_bf16_kernel); `light` a literal at every call site
-    auto fetch = [&](int kc, bool light) {
-        const bool lead = kc < nk0;                           // uniform
-        const int sh = lead ? sh0 : 0;
-        const unsigned o0 = (lead ? (unsigned)kc * KCB : (unsigned)kc * d.in_plane) + chg;
-#pragma unroll
-        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
-        if (light) {
-            wr[CT_K] = wsrc[(tid < CT_N ? tid : 0) + CT_K * NTHR];
-        } else {
-#pragma unroll
-            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * NTHR < WPIECES ? tid + k * NTHR : 0];
-        }
-    };
-    auto commit = [&](bool light) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        if (interior) {                                      // workgroup-uniform
-#pragma unroll
-            for (int k = 0; k < XPER; ++k) {
-                const int item = tid + k * NTHR;
-                if (item < XITEMS) *reinterpret_cast<u32x4*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = xr[k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < XPER; ++k) {
-                const int item = tid + k * NTHR;
-                if (item < XITEMS) *reinterpret_cast<u32x4*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = (okm >> k) & 1 ? xr[k] : z;
-            }
-        }
-        if (light) {
-            if (tid < CT_N) reinterpret_cast<u32x4*>(ws)[tid + CT_K * NTHR] = wr[CT_K];
-        } else {
-#pragma unroll
-            for (int k = 0; k < WPER; ++k)
-                if ((k + 1) * NTHR <= WPIECES || tid + k * NTHR < WPIECES) reinterpret_cast<u32x4*>(ws)[tid + k * NTHR] = wr[k];
-        }
-    };
-    auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(xs + ((2 * wave + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
-    };
-    auto ldW = [&](int tap, int cb) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
-    };
-    auto center_stage = [&]() {                               // the MFMAs of a centre-tap-only chunk
-        bf16x8 p0[2], p1[2], wc[NB];
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) wc[cb] = ldW(TAPS / 2, cb);
-#pragma unroll
-        for (int xh = 0; xh < 2; ++xh) { p0[xh] = ldP(1, xh, 1); p1[xh] = ldP(2, xh, 1); }
-#pragma unroll
-        for (int xh = 0; xh < 2; ++xh)
-#pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-                acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p0[xh], acc[cb][xh], 0, 0, 0);
-                acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[cb], p1[xh], acc[cb][2 + xh], 0, 0, 0);
-            }
-    };
-    auto full_stage = [&]() {                                 // the 72 MFMAs of a full chunk (see conv_bf16_kernel)
-        bf16x8 lo[2], hi[2], wa[NB], wn[NB];
-        lo[0] = ldP(0, 0, 0); lo[1] = ldP(0, 1, 0);
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) wa[cb] = ldW(0, cb);
-        hi[0] = ldP(1, 0, 0); hi[1] = ldP(1, 1, 0);
-#pragma unroll
-        for (int s = 0; s < TAPS; ++s) {
-            const int dy = s % KS;
-            const bool last = s + 1 == TAPS;
-            const int ndx = (s + 1) / KS, ndy = (s + 1) % KS;
-            const bool same_dx = !last && ndy != 0;
-            bf16x8 nlo[2], nhi[2];
-            if (!last) {
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb) wn[cb] = ldW(ndy * KS + ndx, cb);
-            }
-#pragma unroll
-            for (int xh = 0; xh < 2; ++xh) {
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb)
-                    acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], lo[xh], acc[cb][xh], 0, 0, 0);
-                if (same_dx) nhi[xh] = ldP(dy + 2, xh, ndx);
-                else if (!last) nlo[xh] = ldP(0, xh, ndx);
-            }
-#pragma unroll
-            for (int xh = 0; xh < 2; ++xh) {
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb)
-                    acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], hi[xh], acc[cb][2 + xh], 0, 0, 0);
-                if (same_dx) nlo[xh] = hi[xh];
-                else if (!last) nhi[xh] = ldP(1, xh, ndx);
-            }
-            if (!last) {
-#pragma unroll
-                for (int xh = 0; xh < 2; ++xh) { lo[xh] = nlo[xh]; hi[xh] = nhi[xh]; }
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb) wa[cb] = wn[cb];
-            }
-        }
-    };
-    auto decode = [&](int tile, int& n, int& ty, int& tx) {
-        int bt = xcd_tile(tile, ntiles);
-        tx = bt % tilesX; bt /= tilesX;
-        ty = bt % tilesY;
-        n = bt / tilesY;
-    };
-
-    int tile = blockIdx.x;
-    int n, ty, tx;
-    decode(tile, n, ty, tx);
-    geometry(n, ty, tx);
-    if (kcl > 0) fetch(0, true);
-    else fetch(0, false);
-    for (; tile < ntiles; tile += gridDim.x) {
-        // the accumulators start at the bias (BM = 1): nothing of it is live in the epilogue, where the next tile's staging
-        // registers are; lane (c, g) holds channels cb * 16 + 4 g .. + 3
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (BM == 1) b4 = *reinterpret_cast<const f32x4*>(d.bias + a * 16 + 4 * g);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = b4;
-        }
-        // ---- K loop: chunk kc registers -> LDS, chunk kc + 1 memory -> registers, MFMAs of chunk kc
-        int kc = 0;
-        if (kcl > 0) {
-            for (; kc + 1 < kcl; ++kc) {
-                __syncthreads();
-                commit(true);
-                __syncthreads();
-                fetch(kc + 1, true);
-                center_stage();
-            }
-            __syncthreads();
-            commit(true);
-            __syncthreads();
-            if (kc + 1 < nkc) fetch(kc + 1, false);          // the last of them fetches a full slab
-            center_stage();
-            ++kc;
-        }
-        for (; kc + 1 < nkc; ++kc) {
-            __syncthreads();
-            commit(false);
-            __syncthreads();
-            fetch(kc + 1, false);
-            full_stage();
-        }
-        // last chunk: what is fetched behind its commit is chunk 0 of the NEXT tile
-        const int ntile = tile + gridDim.x;
-        const int cn = n, cty = ty, ctx = tx;                 // this tile, for the epilogue
-        __syncthreads();
-        commit(nkc <= kcl);
-        __syncthreads();
-        if (ntile < ntiles) {                                 // (uniform)
-            decode(ntile, n, ty, tx);
-            geometry(n, ty, tx);
-            if (kcl > 0) fetch(0, true);
-            else fetch(0, false);
-        }
-        if (nkc <= kcl) center_stage();
-        else full_stage();
-        // ---- epilogue, written for exactly what the dense layers need (few live registers: the next tile's chunk is in
-        // the staging registers): ReLU and the one-bit masks (BM = 1) or the mask bits applied (BM = 2), the bf16 tile staged in
-        // LDS, whole 64-byte pixel rows stored.  acc[cb][pb]: channels cb * 16 + 4 g .. + 3 of pixel (row 2 wave + (pb >> 1),
-        // x = (pb & 1) * 16 + c).
-        __syncthreads();                                      // every wave is done reading xs / ws
-        // (lane-derived values from an opaque copy of the lane id: hoisted out of the tile loop, the epilogue's bit masks,
-        // addresses and pointers are two dozen registers that live through every K loop)
-        int lv = tid;
-        asm volatile("" : "+v"(lv));
-        const int ew = lv >> 6, ec = lv & 15, eg = (lv >> 4) & 3, el = lv & 63;
-        __bf16* stage = lds + ew * (2 * TW * STAGE_PX);
-        {
-            unsigned pixs[4];
-            unsigned bin[4];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                const int gy = cty * TH_ + 2 * ew + (pb >> 1), gx = ctx * TW + (pb & 1) * 16 + ec;
-                pixs[pb] = gy < H && gx < W ? (unsigned)((cn * H + gy) * W + gx) : 0xffffffffu;
-                if (BM == 2) bin[pb] = d.bits[pixs[pb] == 0xffffffffu ? 0u : pixs[pb]];
-            }
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                unsigned bout = 0;
-#pragma unroll
-                for (int cb = 0; cb < NB; ++cb) {
-                    const int co = cb * 16 + 4 * eg;
-                    float v[4] = {acc[cb][pb][0], acc[cb][pb][1], acc[cb][pb][2], acc[cb][pb][3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (BM == 1) {
-                            v[e] = fmaxf(v[e], 0.f);
-                            bout |= (v[e] > 0.f ? 1u : 0u) << (co + e);
-                        } else if (!((bin[pb] >> (co + e)) & 1u)) {
-                            v[e] = 0.f;
-                        }
-                    }
-                    *reinterpret_cast<bf16x4*>(stage + ((pb >> 1) * TW + (pb & 1) * 16 + ec) * STAGE_PX + co) =
-                        (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                }
-                if (BM == 1) {                                // OR over the 4 lanes (g) of this pixel, lane g = 0 stores the word
-                    bout |= __shfl_xor(bout, 16, 64);
-                    bout |= __shfl_xor(bout, 32, 64);
-                    if (eg == 0 && pixs[pb] != 0xffffffffu) d.bits[pixs[pb]] = bout;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int item = el + k * 64;
-            const int px = item >> 2, piece = item & 3;       // wave-local pixel (2 rows x 32), 8-channel piece
-            const int gy = cty * TH_ + 2 * ew + (px >> 5), gx = ctx * TW + (px & 31);
-            if (gy < H && gx < W)                             // (32-bit element offsets: checked on the host)
-                *reinterpret_cast<u32x4*>(o16 + ((unsigned)((cn * H + gy) * W + gx) * (unsigned)d.out_ld + d.out_coff + 8 * piece)) =
-                    *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX + 8 * piece);
-        }
-        // (the next iteration's first barrier orders these LDS reads before the next commit)
-    }
 }
 
 // ---------------------------------------------------------------- dense-block tail: last 3x3 layer + 1x1 lff, fused
@@ -1118,41 +909,25 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     // and was taken out again: the small parity tests would no longer run the kernel the 540p benchmark runs.)
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && d.tile_rows != 8) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
-        // the dense layers and their mirror-form gradients: persistent workgroups (conv_dense_kernel)
-        const bool dense_common = d.tile_rows != 16 && d.out_bf16 && vec_ok && ncz == 1 && d.cout == 32 && d.cout_store == 32 && !d.res &&
-                                  !d.mask && !d.out2 && !d.accumulate && d.alpha == 1.f && d.cin % KCB == 0 && nkc >= 1 &&
-                                  (d.bits_mode == 1 || d.bits_mode == 2);
-        const bool dense_fwd = dense_common && d.bits_mode == 1 && d.relu && d.bias;
-        const bool dense_bwd = dense_common && d.bits_mode == 2 && !d.relu && !d.bias;
-        if ((dense_fwd || dense_bwd) && (size_t)d.n * d.h * d.w * d.out_ld < ((size_t)1 << 32) && nkc > d.center_cin / KCB) {
-            const long ntl = (long)tilesX * tilesY * d.n;
-            int nwg = ntl < 512 ? (int)ntl : 512;            // two workgroups per CU
-            if (nwg >= 8) nwg &= ~7;                          // multiple of the XCD count: see xcd_tile()
-            if (dense_fwd)
-                hipLaunchKernelGGL(conv_dense_kernel<1>, dim3(nwg), dim3(512), 0, s, d, tilesX, tilesY, (int)ntl, nkc);
-            else
-                hipLaunchKernelGGL(conv_dense_kernel<2>, dim3(nwg), dim3(512), 0, s, d, tilesX, tilesY, (int)ntl, nkc);
-            return check_launch("conv_forward_bf16(dense)");
-        }
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
-                           g_debug_mode & 3);
+                           g_debug_mode & 3, TailArgs{});
         return check_launch("conv_forward_bf16");
     }
     // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
     if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows != 8) {
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8, 2>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
-                           g_debug_mode & 3);
+                           g_debug_mode & 3, TailArgs{});
         return check_launch("conv_forward_bf16");
     }
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), ncz);
 #define NVQ_LAUNCH_CONVB(NB, KS)                                                                                        \
     do {                                                                                                                 \
         if (d.in_bf16)                                                                                                   \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);   \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3, TailArgs{});   \
         else                                                                                                             \
-            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3);  \
+            hipLaunchKernelGGL((conv_bf16_kernel<NB, KS, false>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, vec_ok, g_debug_mode & 3, TailArgs{});  \
     } while (0)
     if (d.ksize == 3) {
         if (NT == 16) NVQ_LAUNCH_CONVB(1, 3);
@@ -1165,6 +940,25 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     }
 #undef NVQ_LAUNCH_CONVB
     return check_launch("conv_forward_bf16");
+}
+
+// conv 3x3 (cin -> Cimg * s * s, bf16 input) + PixelShuffle(s) + bicubic skip + clamp in one launch
+int upsampler_tail_bf16(const nvq_conv_desc& d, const float* frames, int T, int t_center, int Cimg, int s, float* out,
+                        unsigned char* pass, hipStream_t st) {
+    NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32), "upsampler_tail: tensor exceeds 32-bit offsets");
+    const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
+    const int nkc = (d.cin + KCB - 1) / KCB;
+    const dim3 grid((unsigned)((long)tilesX * tilesY * d.n), 1);
+    const TailArgs t{frames, out, pass, T, t_center, Cimg};
+    if (s == 2 && Cimg * 4 <= 16)
+        hipLaunchKernelGGL((conv_bf16_kernel<1, 3, true, 4, 1, 2>), grid, dim3(256), 0, st, d, tilesX, tilesY, nkc, 0, 0, t);
+    else if (s == 3 && Cimg * 9 <= 32)
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 4, 1, 3>), grid, dim3(256), 0, st, d, tilesX, tilesY, nkc, 0, 0, t);
+    else if (s == 4 && Cimg * 16 <= 64)
+        hipLaunchKernelGGL((conv_bf16_kernel<4, 3, true, 4, 1, 4>), grid, dim3(256), 0, st, d, tilesX, tilesY, nkc, 0, 0, t);
+    else
+        NVQ_REQUIRE(false, "upsampler_tail: scale %d with %d image channels", s, Cimg);
+    return check_launch("upsampler_tail_forward");
 }
 
 // resident workgroups per CU of the three heaviest kernels as the runtime computes them (tools/kernel_phases.py)

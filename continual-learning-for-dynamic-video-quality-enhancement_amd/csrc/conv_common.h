@@ -31,6 +31,8 @@ PackJobDev pack_job_bf16(const nvq_pack_job& j);
 int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s);
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s);
+int upsampler_tail_bf16(const nvq_conv_desc& d, const float* frames, int T, int t_center, int Cimg, int s, float* out,
+                        unsigned char* pass, hipStream_t st);
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s);
 
 // Bias-gradient partials of the wgrad kernels: every thread holds the column sums of the dy pieces it staged

@@ -619,6 +619,18 @@ int nvq_rdb_tail_forward(const nvq_conv_desc* d3p, const nvq_conv_desc* dlp, voi
     return rdb_tail_bf16(d3, dl, vec3, vecl, (hipStream_t)stream);
 }
 
+int nvq_upsampler_tail_forward(const nvq_conv_desc* dp, const float* frames, int T, int t_center, int Cimg, int s, float* out,
+                               uint8_t* pass, void* stream) {
+    const nvq_conv_desc d = *dp;
+    NVQ_REQUIRE(d.math == NVQ_MATH_BF16 && d.in_bf16 && d.ksize == 3, "upsampler_tail_forward: NVQ_MATH_BF16, bf16 input, 3x3 only");
+    NVQ_REQUIRE(d.cin > 0 && d.cin % 8 == 0 && d.in_ld % 8 == 0 && d.in_coff % 8 == 0 && aligned16(d.in) && !d.in_plane,
+                "upsampler_tail_forward: input must be a 16-byte addressable bf16 slice");
+    NVQ_REQUIRE(s >= 2 && s <= 4 && Cimg >= 1 && d.cout == Cimg * s * s && t_center >= 0 && t_center < T && frames && out && pass,
+                "upsampler_tail_forward: cout %d for %d image channels at scale %d", d.cout, Cimg, s);
+    NVQ_REQUIRE(aligned16(d.wpack) && d.n > 0 && d.h > 0 && d.w > 0 && d.center_cin == 0, "upsampler_tail_forward: args");
+    return upsampler_tail_bf16(d, frames, T, t_center, Cimg, s, out, pass, (hipStream_t)stream);
+}
+
 int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
     const nvq_conv_desc d = *dp;
     NVQ_REQUIRE(d.math == NVQ_MATH_F32 || d.math == NVQ_MATH_BF16, "conv_forward: math mode %d", d.math);

@@ -32,6 +32,13 @@ _ws_cache: Dict[torch.device, torch.Tensor] = {}
 DEBUG_CAPTURE: Optional[dict] = None
 
 
+def _fused_tail_ok(math: int, x: torch.Tensor, Cimg: int, scale: int) -> bool:
+    """nvq_upsampler_tail_forward's domain: bf16 MFMA mode, a bf16-stored input, scale 2..4 with Cimg * scale^2 <= 16 / 32 / 64.
+    (The exact-fp32 mode keeps the conv + nvq_shuffle_bicubic_clamp pair; NVQ_FUSED_TAIL=0 selects it in bf16 mode too.)"""
+    return (math == K.MATH_BF16 and x.dtype == torch.bfloat16 and scale in (2, 3, 4)
+            and Cimg * scale * scale <= {2: 16, 3: 32, 4: 64}[scale] and os.environ.get("NVQ_FUSED_TAIL", "1") != "0")
+
+
 def _capture(name: str, t) -> None:
     """t: a tensor, or a callable producing one (evaluated only while a capture is requested)"""
     if DEBUG_CAPTURE is not None:
@@ -223,7 +230,8 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     # bf16 mode: the dense layers also emit their ReLU masks as one bit per channel (4 B per pixel) for the backward
     use_bits = training and act_dtype == torch.bfloat16
     sv.bits = [[_new(dev, B, H, W, dtype=torch.int32) for _ in range(LAYERS)] for _ in range(nblocks)] if use_bits else None
-    fuse_tail = act_dtype == torch.bfloat16 and F == 64      # last dense layer + lff in one pass over the concat buffer
+    fuse_tail = (act_dtype == torch.bfloat16 and F == 64        # last dense layer + lff in one pass over the concat buffer
+                 and os.environ.get("NVQ_FUSE_TAIL", "1") != "0")
     for k in range(nblocks):
         cat = cats[k]
         for i in range(LAYERS - 1 if fuse_tail else LAYERS):
@@ -249,12 +257,16 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     fused, gr = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)   # conv-to-conv tensors
     K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F, math=math), P["gff.0.bias"], Sl(fused), 3,
                    relu=True, out2=Sl(gr), res=center, math=math)
-    u = _new(dev, B, H, W, g.Up)
-    K.conv_forward(Sl(fused), K.conv_pack(P["upsampler.conv.weight"], False, F, math=math), P["upsampler.conv.bias"],
-                   Sl(u, g.U), 3, cout_store=g.Up, math=math)
     out = _new(dev, B, g.Cimg, H * scale, W * scale)
     passmask = _new(dev, B, g.Cimg, H * scale, W * scale, dtype=torch.uint8)
-    K.shuffle_bicubic_clamp(u, frames, c, scale, out, passmask)
+    wup = K.conv_pack(P["upsampler.conv.weight"], False, F, math=math)
+    if _fused_tail_ok(math, fused, g.Cimg, scale):
+        # conv + pixel-shuffle (an LDS transpose in the conv's epilogue) + bicubic skip + clamp: one launch, no `u` tensor
+        K.upsampler_tail_forward(Sl(fused), wup, P["upsampler.conv.bias"], frames, c, scale, out, passmask)
+    else:
+        u = _new(dev, B, H, W, g.Up)
+        K.conv_forward(Sl(fused), wup, P["upsampler.conv.bias"], Sl(u, g.U), 3, cout_store=g.Up, math=math)
+        K.shuffle_bicubic_clamp(u, frames, c, scale, out, passmask)
     sv.fused, sv.gr, sv.passmask = fused, gr, passmask
     sv.xloc = xloc
     return out, sv
@@ -491,12 +503,15 @@ def light_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, scale: int, train
         cur = r
     U = Cimg * scale * scale
     Up = K.pad4(U)
-    u = _new(dev, B, H, W, Up)
-    K.conv_forward(Sl(cur), K.conv_pack(P["net.6.weight"], False, F, math=math), P["net.6.bias"], Sl(u, U), 3,
-                   cout_store=Up, math=math)
     out = _new(dev, B, Cimg, H * scale, W * scale)
     passmask = _new(dev, B, Cimg, H * scale, W * scale, dtype=torch.uint8)
-    K.shuffle_bicubic_clamp(u, frames, 0, scale, out, passmask)
+    wup = K.conv_pack(P["net.6.weight"], False, F, math=math)
+    if _fused_tail_ok(math, cur, Cimg, scale):
+        K.upsampler_tail_forward(Sl(cur), wup, P["net.6.bias"], frames, 0, scale, out, passmask)
+    else:
+        u = _new(dev, B, H, W, Up)
+        K.conv_forward(Sl(cur), wup, P["net.6.bias"], Sl(u, U), 3, cout_store=Up, math=math)
+        K.shuffle_bicubic_clamp(u, frames, 0, scale, out, passmask)
     sv.passmask, sv.U, sv.Up = passmask, U, Up
     return out, sv
 

@@ -105,6 +105,7 @@ SIGNATURES = {
     "nvq_cbam_bwd_spatial_conv": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, sz, ci, vp]),
     "nvq_cbam_bwd_scale": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
     "nvq_cbam_bwd_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "nvq_upsampler_tail_forward": (ci, [C.POINTER(ConvDesc), vp, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_clamp_backward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_bicubic_blend": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]),
@@ -722,6 +723,26 @@ def cbam_bwd_channel(dca_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca, dw1,
 
 
 # ----------------------------------------------------------------------------- upsampler tail
+def upsampler_tail_forward(x: Sl, wpack: torch.Tensor, bias: torch.Tensor, frames: torch.Tensor, t_center: int, s: int, out,
+                           passmask) -> None:
+    """conv3x3(x -> Cimg*s*s) + PixelShuffle(s) + bicubic skip + clamp in one launch (bf16 mode, bf16 x)."""
+    B, T, Cimg, H, W = frames.shape
+    n, h, w, _ = x.t.shape
+    assert (n, h, w) == (B, H, W)
+    ev0 = TIMER.start() if TIMER is not None else None
+    d = ConvDesc()
+    d.inp, d.in_ld, d.in_coff, d.cin = ptr(x.t), x.ld, x.coff, x.c
+    d.wpack, d.bias = ptr(wpack), ptr(bias)
+    d.cout = d.cout_store = Cimg * s * s
+    d.n, d.h, d.w, d.ksize, d.alpha, d.math, d.in_bf16 = n, h, w, 3, 1.0, MATH_BF16, x.bf16
+    check(lib().nvq_upsampler_tail_forward(C.byref(d), ptr(frames), T, t_center, Cimg, s, ptr(out), ptr(passmask), stream()),
+          "nvq_upsampler_tail_forward")
+    if ev0 is not None:
+        U = Cimg * s * s
+        TIMER.stop(ev0, "upsampler_tail_kernel", 2.0 * n * h * w * x.c * 9 * U,
+                   n * h * w * (x.c * 2.0 + Cimg * 4.0 + Cimg * s * s * 5.0), f"n{n} cin{x.c}h s{s}")
+
+
 def shuffle_bicubic_clamp(u: torch.Tensor, frames: torch.Tensor, t_center: int, s: int, out, passmask):
     B, T, Cimg, H, W = frames.shape
     check(lib().nvq_shuffle_bicubic_clamp(ptr(u), u.shape[-1], ptr(frames), B, T, t_center, Cimg, H, W, s,

@@ -109,8 +109,7 @@ typedef struct nvq_conv_desc {
     unsigned in_plane;
     /* Kernel-variant hint, results do not depend on it: 0 = automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their
      * 8x32-pixel, four-wave form (the automatic choice for bf16 input is the eight-wave form: 16x32 tiles for cout <= 32,
-     * two 32-channel halves per workgroup for cout >= 64); 16 = the eight-wave form with one tile per workgroup also where the
-     * library would run its persistent dense-layer kernel.  Lets a caller A/B the forms without any library state. */
+     * two 32-channel halves per workgroup for cout >= 64).  Lets a caller A/B the two forms without any library state. */
     int tile_rows;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
@@ -329,6 +328,14 @@ int nvq_cbam_bwd_channel(const float* dca_partial, int nblk, int C, int R, int N
                          const float* w1, const float* w2, const float* gap, const float* hid,
                          const float* ca, float* dw1, float* dw2, float* dgap_pix,
                          int accumulate, void* stream);
+
+/* The whole upsampler tail in one launch (NVQ_MATH_BF16, bf16 input): PixelShuffleUpsampler.conv (3x3, cin -> Cimg*s*s, bias;
+ * efficient_layers.py:94-100) whose epilogue puts the tile's conv outputs through LDS, reads them back as s x s pixel blocks
+ * (PixelShuffle, :101-106), adds the bicubic skip of frames[:, t_center] and clamps (super_resolution.py:378-382): the
+ * conv output never exists as a tensor.  d: in / wpack / bias / cin / cout = Cimg*s*s / n, h, w (output fields unused);
+ * out, pass as nvq_shuffle_bicubic_clamp below, to which (after nvq_conv_forward) the result is bit-identical.  s in {2, 3, 4}. */
+int nvq_upsampler_tail_forward(const nvq_conv_desc* d, const float* frames, int T, int t_center, int Cimg, int s,
+                               float* out, uint8_t* pass, void* stream);
 
 /* ------------------------------------------------------------------ upsampler tail
  * PixelShuffle(s) + bicubic skip + clamp, efficient_layers.py:101-106 and

@@ -413,6 +413,36 @@ def test_cbam_forward_backward(K, C, B, H, W):
 
 
 # ----------------------------------------------------------------------------- upsampler tail
+@pytest.mark.parametrize("s,cin,B,T,H,W", [(2, 64, 2, 3, 19, 45), (3, 32, 1, 3, 8, 32), (4, 64, 1, 5, 17, 33), (2, 32, 3, 3, 9, 14)])
+def test_upsampler_tail_fused_in_the_conv_epilogue(K, s, cin, B, T, H, W):
+    """nvq_upsampler_tail_forward (bf16 mode): the 3x3 conv to 3 s^2 channels with the pixel shuffle done as an LDS transpose
+    in its epilogue, the bicubic skip and the clamp - against the reference ops (PixelShuffleUpsampler
+    efficient_layers.py:94-106, super_resolution.py:378-382) and, bit for bit, against the two-kernel path
+    (nvq_conv_forward + nvq_shuffle_bicubic_clamp); interior and border tiles, all three scales."""
+    U = 3 * s * s
+    frames = rnd(B, T, 3, H, W, seed=1).abs()
+    x = bf(rnd(B, cin, H, W, seed=2))
+    w, b = rnd(U, cin, 3, 3, scale=0.08, seed=3), rnd(U, seed=4) * 0.1
+    xb = to_nhwc_bf16(x)
+    wp = K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16)
+    out = torch.empty(B, 3, H * s, W * s, device="cuda")
+    pm = torch.empty(B, 3, H * s, W * s, dtype=torch.uint8, device="cuda")
+    K.upsampler_tail_forward(K.Sl(xb), wp, b.cuda(), frames.cuda(), T // 2, s, out, pm)
+    Up = K.pad4(U)
+    u = torch.zeros(B, H, W, Up, device="cuda")
+    K.conv_forward(K.Sl(xb), wp, b.cuda(), K.Sl(u, U), 3, cout_store=Up, math=K.MATH_BF16)
+    out2 = torch.empty_like(out)
+    pm2 = torch.empty_like(pm)
+    K.shuffle_bicubic_clamp(u, frames.cuda(), T // 2, s, out2, pm2)
+    assert torch.equal(out, out2) and torch.equal(pm, pm2)
+    pre = sr_oracle.bicubic_up(frames[:, T // 2], s) + F.pixel_shuffle(F.conv2d(x, bf(w), b, padding=1), s)
+    assert (out.cpu() - pre.clamp(0, 1)).abs().max().item() < 2e-5
+    frac = ((out == 0) | (out == 1)).float().mean().item()
+    assert 0.02 < frac < 0.9
+    with pytest.raises(RuntimeError, match="upsampler_tail"):   # the exact-fp32 mode has no fused form
+        K.upsampler_tail_forward(K.Sl(to_nhwc(x)), wp, b.cuda(), frames.cuda(), T // 2, s, out, pm)
+
+
 @pytest.mark.parametrize("s,B,T,H,W", [(2, 2, 3, 9, 14), (3, 1, 3, 7, 11), (4, 1, 5, 6, 10)])
 def test_shuffle_bicubic_clamp(K, s, B, T, H, W):
     frames = rnd(B, T, 3, H, W).abs()
