@@ -6,7 +6,10 @@ Declared deviation: the reference script crashes at its first ``
 ``EWC.compute_fisher`` feeds the 4-D loader batch to ``EnhancementEngine.forward`` (which needs 5-D input and
 returns a dict).  Here EWC wraps a thin adapter around the same engine that maps (B,C,H,W) -> (B,3,C,H,W) and
 returns ``['enhanced']``, so the Fisher / penalty actually run; everything up to that point prints what the
-reference prints.  ``--tasks`` / ``--samples`` / ``--epochs`` are additions (defaults = the reference's values)."""
+reference prints.  ``--tasks`` / ``--samples`` / ``--epochs`` are additions (defaults = the reference's values), and so are
+``--precision`` / ``--graphs``: 64x64 clips are launch-bound on an MI355X, so the script runs the network
+in its throughput mode by default - bf16 MFMA operands with fp32 accumulation and, for such small frames, HIP-graph replay of the
+step (``net.use_hip_graphs = "auto"``); ``--precision fp32 --graphs off`` is the exact-fp32 parity mode the package defaults to."""
 import argparse
 from pathlib import Path
 
@@ -37,6 +40,16 @@ class _ClipAdapter(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.engine(x.unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+
+
+def configure_precision(model: EnhancementEngine, precision: str, graphs: str) -> None:
+    """The script's precision / replay choice applied to the engine's SR network (knobs of nerve_cl.models.SuperResolutionNet,
+    not part of the reference surface)."""
+    from nerve_cl import _nvq
+    sr = model.super_resolution
+    sr.math_mode = _nvq.MATH_BF16 if precision == "bf16" else _nvq.MATH_F32
+    sr.bf16_activations = precision == "bf16"
+    sr.use_hip_graphs = {"auto": "auto", "on": True, "off": False}[graphs]
 
 
 def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
@@ -105,6 +118,10 @@ def main() -> None:
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--features", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=8)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="MFMA operand precision of the convolutions (accumulation fp32; fp32 = the exact parity mode)")
+    ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
+                    help="HIP-graph replay of the training step (auto: for launch-bound frame sizes only)")
     args = ap.parse_args()
 
     device, rank, world = pick_device()
@@ -112,6 +129,7 @@ def main() -> None:
     model = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True,
                                                 sr_num_features=args.features,
                                                 sr_num_residual_blocks=args.blocks)).to(device)
+    configure_precision(model, args.precision, args.graphs)
     if world > 1:
         parallel.enable_data_parallel(model)
     tasks = [(ct, create_task_data(ct, args.samples)) for ct in list(OFFSETS)[:args.tasks]]

@@ -1,0 +1,53 @@
+"""GPU box: time per training step of experiments/train_continual.py's EWC loop (engine defaults F=64, 8 blocks, T=3, 64x64
+clips, Adam, loss = mse + penalty after a first registered task) in the script's default mode and in the parity mode."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "experiments")); sys.path.insert(0, os.path.join(REPO, "continual-learning-for-dynamic-video-quality-enhancement_amd"))
+import torch
+import train_continual as TC
+from nerve_cl import ops
+from nerve_cl.continual import EWC
+from nerve_cl.models import EnhancementConfig, EnhancementEngine
+
+dev = torch.device("cuda", 0)
+for precision, graphs in (("bf16", "auto"), ("bf16", "off"), ("fp32", "auto"), ("fp32", "off")):
+    for batch in (8, 16):
+        torch.manual_seed(0)
+        model = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True)).to(dev)
+        TC.configure_precision(model, precision, graphs)
+        adapter = TC._ClipAdapter(model)
+        ewc = EWC(adapter, ewc_lambda=5000)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        crit = ops.MSELoss()
+        lr, hr = TC.create_task_data("sports", 64)
+        lr, hr = lr.to(dev), hr.to(dev)
+        loader = [(lr[i:i + batch], hr[i:i + batch]) for i in range(0, 64, batch)]
+
+        def step(a, b):
+            opt.zero_grad()
+            out = model(a.unsqueeze(1).expand(-1, 3, -1, -1, -1))["enhanced"]
+            loss = crit(out, b) + ewc.penalty()
+            loss.backward()
+            opt.step()
+            return loss
+
+        model.train()
+        for a, b in loader[:3]:
+            step(a, b)
+        ewc.register_task(0, loader[:2])
+        model.train()
+        for _ in range(4):
+            for a, b in loader:
+                step(a, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(6):
+            for a, b in loader:
+                loss = step(a, b)
+                n += 1
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        g = model.super_resolution._step_graphs
+        print(f"precision {precision} graphs {graphs:4s} batch {batch:2d}: {dt:6.2f} ms per step  (replays {g.replays}, eager fallbacks "
+              f"{g.eager_fallbacks}, loss {loss.item():.4f})", flush=True)
