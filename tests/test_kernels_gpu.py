@@ -627,7 +627,11 @@ def test_conv_bf16_stored_dense_block_epilogues(K):
 
 @pytest.mark.parametrize("xb,yb", [(True, True), (True, False), (False, True)])
 @pytest.mark.parametrize("cin,cout,k,N,H,W", [(64, 32, 3, 2, 16, 40), (224, 64, 1, 1, 11, 37), (192, 64, 3, 1, 8, 64),
-                                              (96, 72, 1, 2, 9, 33), (64, 128, 1, 1, 17, 32)])
+                                              (96, 72, 1, 2, 9, 33), (64, 128, 1, 1, 17, 32),
+                                              # an odd number of 32-channel units: 64-channel chunks + a 32-channel tail with
+                                              # its own pixel-split count in one launch (wgrad_bf16_mixed_kernel)
+                                              (96, 32, 3, 2, 19, 70), (160, 32, 3, 3, 33, 41), (96, 128, 3, 2, 24, 33),
+                                              (224, 64, 3, 1, 17, 50)])
 def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     x, dy = bf(rnd(N, cin, H, W)), bf(rnd(N, cout, H, W, seed=3))
     w = rnd(cout, cin, k, k).requires_grad_()
