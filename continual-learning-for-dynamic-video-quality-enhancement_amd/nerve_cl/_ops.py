@@ -780,6 +780,71 @@ class Correlation(torch.autograd.Function):
         return dx1, dx2, None
 
 
+class ScaleAdd(torch.autograd.Function):
+    """alpha * a + b over the first C channels of two [N,H,W,ld] tensors (the `features = body(h) + h` skip of the feature
+    extractor, super_resolution.py:53, and the 0.2-scaled residual of a dense block, :253)"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha: float):
+        assert a.shape == b.shape
+        y = b.clone()
+        K.axpy_slice(Sl(y), Sl(a), float(alpha), accumulate=True)
+        ctx.alpha = float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = torch.empty_like(dy)
+        K.axpy_slice(Sl(da), Sl(dy), ctx.alpha, accumulate=False)
+        return da, dy, None
+
+
+class SoftmaxWeightedSum(torch.autograd.Function):
+    """TemporalAggregator's  softmax over the T attention logits + sum_t aligned_t * attn_t  (super_resolution.py:174,
+    203-204).  aligned [N,H,W,T*C] frame-major, logits [N,H,W,>=T] -> weighted [N,H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, aligned, logits, T: int, C: int):
+        N, H, W, _ = aligned.shape
+        attn, weighted = _new(aligned, N, H, W, K.pad4(T)), _new(aligned, N, H, W, C)
+        gap_partial = _new(aligned, N, K.tsum_blocks(H, W), C)
+        K.tsum_forward(aligned, logits, T, C, attn, weighted, gap_partial)
+        ctx.save_for_backward(aligned, attn)
+        ctx.T, ctx.C, ctx.lp = T, C, logits.shape[-1]
+        return weighted
+
+    @staticmethod
+    def backward(ctx, dweighted):
+        aligned, attn = ctx.saved_tensors
+        N, H, W, _ = aligned.shape
+        dweighted = dweighted.contiguous()
+        daligned, dlogits = torch.empty_like(aligned), _new(aligned, N, H, W, ctx.lp, zero=True)
+        K.tsum_backward(dweighted, _new(aligned, N, ctx.C, zero=True), aligned, attn, ctx.T, ctx.C, daligned, dlogits)
+        return daligned, dlogits, None, None
+
+
+class Warp(torch.autograd.Function):
+    """warp_features (super_resolution.py:104-143): bilinear sampling of `feat` at (x + flow_x, y + flow_y), zero padding,
+    align_corners=True; gradients to the features and to the flow.  feat [N,H,W,ld] (C channels), flow [N,H,W,4]."""
+
+    @staticmethod
+    def forward(ctx, feat, flow, C: int):
+        out = _new(feat, *feat.shape, zero=feat.shape[-1] > C)
+        K.warp_forward(Sl(feat, C), flow, Sl(out, C))
+        ctx.save_for_backward(feat, flow)
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, flow = ctx.saved_tensors
+        dout = dout.contiguous()
+        dfeat, dflow = torch.zeros_like(feat), torch.zeros_like(flow)
+        K.warp_backward(Sl(dout, ctx.C), Sl(feat, ctx.C), flow, Sl(dfeat, ctx.C), dflow)
+        return dfeat, dflow, None
+
+
 # ----------------------------------------------------------------------------- functional helpers used by the modules
 def bn(x, mod, training: bool, relu: bool, res=None):
     """apply an nn.BatchNorm2d / BatchNorm3d holder `mod` (its buffers are updated in place in training mode)"""

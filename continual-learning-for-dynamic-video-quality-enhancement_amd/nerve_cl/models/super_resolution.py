@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from nerve_cl import _engine, _graphs, _nvq
+from nerve_cl import _engine, _graphs, _nvq, _ops
 from nerve_cl._bucket import BucketedNet
 from nerve_cl.models.layers import (
     CBAM,
@@ -26,7 +26,12 @@ from nerve_cl.models.layers import (
     Stack,
     Act,
 )
-from nerve_cl.models.layers.efficient_layers import _Holder
+from nerve_cl.models.layers.efficient_layers import _Holder, _nchw_call
+
+# The four sub-modules below are parameter holders inside SuperResolutionNet (whose forward / backward is ONE fused kernel
+# schedule, nerve_cl._engine).  Called on their own - the reference's classes are ordinary nn.Modules - they compute through
+# the same libnvq kernels, chained by the differentiable ops of nerve_cl._ops (exact-fp32 mode, fp32 NCHW tensors in and out
+# like the reference; no CPU / PyTorch fallback).
 
 
 class FeatureExtractor(_Holder):
@@ -36,6 +41,18 @@ class FeatureExtractor(_Holder):
         super().__init__()
         self.head = Stack(nn.Conv2d(in_channels, num_features, 3, 1, 1), Act())
         self.body = Stack(*[DepthwiseSeparableConv(num_features, num_features) for _ in range(3)])
+        self.num_features = num_features
+
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        h = _ops.Conv.apply(x, self.head[0].weight, self.head[0].bias, True, _nvq.MATH_F32)
+        y = h
+        for blk in self.body:
+            y = blk.forward_nhwc(y)
+        return _ops.ScaleAdd.apply(y, h, 1.0)                 # features = body(h) + h  (reference :53)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N, C, H, W) frame -> (N, F, H, W) features (reference :51-54)"""
+        return _nchw_call(self.forward_nhwc, x, self.num_features)
 
 
 class MotionEstimator(_Holder):
@@ -46,6 +63,21 @@ class MotionEstimator(_Holder):
         self.correlation = LiteFlowNetCorrelation(max_displacement=4)
         self.flow_net = Stack(nn.Conv2d(81, 128, 3, 1, 1), Act(), nn.Conv2d(128, 64, 3, 1, 1), Act(),
                               nn.Conv2d(64, 32, 3, 1, 1), Act(), nn.Conv2d(32, 2, 3, 1, 1))
+        self.in_channels = in_channels
+
+    def forward(self, feat1: torch.Tensor, feat2: torch.Tensor) -> torch.Tensor:
+        """(N, F, H, W) x 2 -> (N, 2, H, W) flow, channel 0 = dx, 1 = dy (reference :84-101)"""
+        _nvq.require_device(feat1, "feat1")
+        _nvq.require_device(feat2, "feat2")
+        if feat1.dim() != 4 or feat1.shape != feat2.shape:
+            raise RuntimeError(f"expected two (N,C,H,W) tensors of one shape, got {tuple(feat1.shape)} and {tuple(feat2.shape)}")
+        C = feat1.shape[1]
+        with _nvq.device_guard(feat1.device):
+            y = _ops.Correlation.apply(_ops.ToNHWC.apply(feat1), _ops.ToNHWC.apply(feat2), C)
+            for i in (0, 2, 4, 6):
+                conv = self.flow_net[i]
+                y = _ops.Conv.apply(y, conv.weight, conv.bias, i != 6, _nvq.MATH_F32)
+            return _ops.ToNCHW.apply(y, 2)
 
 
 class TemporalAggregator(_Holder):
@@ -58,6 +90,25 @@ class TemporalAggregator(_Holder):
                                nn.Conv2d(num_features, num_features, 3, 1, 1), Act(),
                                nn.Conv2d(num_features, num_frames, 3, 1, 1), Act())
         self.refine = CBAM(num_features)
+        self.num_features = num_features
+
+    def forward(self, aligned_features: List[torch.Tensor]) -> torch.Tensor:
+        """T aligned (N, F, H, W) feature maps -> (N, F, H, W) (reference :180-209)"""
+        T, C = self.num_frames, self.num_features
+        if len(aligned_features) != T:
+            raise RuntimeError(f"expected {T} aligned feature maps, got {len(aligned_features)}")
+        for f in aligned_features:
+            _nvq.require_device(f, "aligned features")
+        with _nvq.device_guard(aligned_features[0].device):
+            cat = _ops.ToNHWC.apply(aligned_features[0])
+            for f in aligned_features[1:]:
+                cat = _ops.Cat2.apply(cat, _ops.ToNHWC.apply(f))
+            a = cat
+            for i in (0, 2, 4):
+                conv = self.attention[i]
+                a = _ops.Conv.apply(a, conv.weight, conv.bias, i != 4, _nvq.MATH_F32)
+            weighted = _ops.SoftmaxWeightedSum.apply(cat, a, T, C)
+            return _ops.ToNCHW.apply(self.refine.forward_nhwc(weighted), C)
 
 
 class ResidualDenseBlock(_Holder):
@@ -73,6 +124,32 @@ class ResidualDenseBlock(_Holder):
             self.layers.append(Stack(nn.Conv2d(ch, growth_rate, 3, 1, 1), Act()))
             ch += growth_rate
         self.lff = nn.Conv2d(ch, num_features, 1)
+        self.num_features = num_features
+
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        cat = x
+        for layer in self.layers:
+            y = _ops.Conv.apply(cat, layer[0].weight, layer[0].bias, True, _nvq.MATH_F32)
+            cat = _ops.Cat2.apply(cat, y)
+        out = _ops.Conv.apply(cat, self.lff.weight, self.lff.bias, False, _nvq.MATH_F32)
+        return _ops.ScaleAdd.apply(out, x, 0.2)                # local residual learning, scaled (reference :253)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N, F, H, W) -> (N, F, H, W) (reference :245-253)"""
+        return _nchw_call(self.forward_nhwc, x, self.num_features)
+
+
+def warp_features(features: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+    """Reference super_resolution.py:104-143: sample `features` (N, C, H, W) at pixel coordinates (x + flow[:, 0],
+    y + flow[:, 1]) - bilinear, zeros outside the image, align_corners=True.  Differentiable w.r.t. both arguments."""
+    _nvq.require_device(features, "features")
+    _nvq.require_device(flow, "flow")
+    if features.dim() != 4 or flow.dim() != 4 or flow.shape[1] != 2 or flow.shape[0] != features.shape[0] \
+            or flow.shape[2:] != features.shape[2:]:
+        raise RuntimeError(f"expected (N,C,H,W) features and (N,2,H,W) flow, got {tuple(features.shape)} and {tuple(flow.shape)}")
+    C = features.shape[1]
+    with _nvq.device_guard(features.device):
+        return _ops.ToNCHW.apply(_ops.Warp.apply(_ops.ToNHWC.apply(features), _ops.ToNHWC.apply(flow), C), C)
 
 
 class _SRFunction(torch.autograd.Function):
