@@ -77,8 +77,10 @@ def test_cpu_forward_is_refused_loudly():
         m(torch.rand(1, 3, 3, 8, 8))
     with pytest.raises(ValueError):
         m(torch.rand(1, 3, 8, 8))          # 4-D input: tuple-unpack error like the reference
-    with pytest.raises(RuntimeError, match="only holds parameters"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # the sub-modules compute on their own - on HIP tensors
         m.feature_extractor(torch.rand(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="only holds parameters"):
+        m.residual_blocks(torch.rand(1, 16, 8, 8))               # a plain container of the reference's nn.Sequential shape
 
 
 def test_engine_surface():
