@@ -399,6 +399,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     }
 }
 
+// (for kernels of other translation units that write partial slabs in this layout: pw_bwd.hip)
+int launch_wgrad_reduce(const float* part, int nsplit, int nci, int nco, int taps, int cout, int cin_w, float alpha,
+                        int accumulate, float* dw, hipStream_t s) {
+    const long total = (long)nci * nco * taps * WG_C * WG_C;
+    int nblk = ceil_div(total, 256);
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, part, nsplit, nci, nco, taps, cout, cin_w, alpha,
+                       accumulate, dw);
+    return check_launch("conv_wgrad_reduce");
+}
+
 // one wave per output channel: sums bias_part[split][coc][32] over the splits in double
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int nco,
                                                                 int cout, float alpha, int accumulate,

@@ -1079,6 +1079,26 @@ static bool pow2_c4(int C) {
     const int c4 = C >> 2;
     return C % 4 == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0;
 }
+static int blocks_for(long npix, int C);
+
+// BatchNorm backward, first half: the per-group sums  sum(g), sum(g xhat)  (g = dy masked by relu(bn(x)) > 0) in
+// sums[G][2C] inside the workspace, and dgamma / dbeta.  Used by nvq_bn_relu_backward and nvq_pw_bn_backward (pw_bwd.hip).
+int bn_backward_sums(const float* dy, int dy_ld, const float* x, int x_ld, int C, int G, long group_pix, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* workspace,
+                     size_t workspace_bytes, int dy_bf16, int x_bf16, float** sums_out, hipStream_t s) {
+    const int nblk = blocks_for(group_pix, C);
+    const size_t part_floats = (size_t)G * nblk * 2 * C;
+    if ((part_floats + (size_t)G * 2 * C) * sizeof(float) > workspace_bytes) { set_error("bn backward: workspace"); return NVQ_EWORKSPACE; }
+    float* sums = workspace + part_floats;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, G), dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, mean,
+                       invstd, gamma, beta, dy_bf16, x_bf16, workspace);
+    int rc = check_launch("bn_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, sums, dgamma, dbeta, 0);
+    *sums_out = sums;
+    return check_launch("bn_bwd_finalize");
+}
+
 static int blocks_for(long npix, int C) {
     const int npl = 256 / (C >> 2);
     int nb = ceil_div(npix, (long)npl * 16);

@@ -439,12 +439,20 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dcur = dfeat_all
     for k in (2, 1, 0):
         pre = f"feature_extractor.body.{k}."
-        dp = _new(dev, NI, H, W, F, dtype=act_dtype)
-        K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
-                           P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
-        _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
         dd = _new(dev, NI, H, W, F, dtype=act_dtype)
-        K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
+        if (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F == 64 and sv.pws[k].dtype == torch.bfloat16
+                and sv.dws[k].dtype == torch.bfloat16 and os.environ.get("NVQ_FUSED_PW_BWD", "1") != "0"):
+            # BatchNorm backward + the pointwise conv's input and weight gradients in one pass behind the BatchNorm sums: dp is
+            # formed in LDS and never stored (nvq_pw_bn_backward)
+            K.pw_bn_backward(dcur, sv.pws[k], sv.dws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
+                             P[pre + "bn.bias"], sv.training, P[pre + "pointwise.weight"], dd, G[pre + "bn.weight"],
+                             G[pre + "bn.bias"], G[pre + "pointwise.weight"], ws)
+        else:
+            dp = _new(dev, NI, H, W, F, dtype=act_dtype)
+            K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
+                               P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
+            _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
+            K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin, xin_bn = sv.dw_in[k]
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws, bn=xin_bn)
         if k == 0 and sv.img8 is not None:

@@ -91,6 +91,7 @@ SIGNATURES = {
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
+    "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
@@ -620,6 +621,22 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
                                      ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), is_bf16(dy),
                                      is_bf16(x), is_bf16(dx), stream()),
           "nvq_bn_relu_backward")
+
+
+def pw_bn_backward(dy: torch.Tensor, p: torch.Tensor, d: torch.Tensor, group_images: int, mean, invstd, gamma, beta,
+                   training: bool, weight: torch.Tensor, dd: torch.Tensor, dgamma, dbeta, dweight, ws) -> None:
+    """Backward of pointwise conv -> BatchNorm -> ReLU in one pass (bf16 mode, 64 channels): see nvq_pw_bn_backward."""
+    N, H, W, _ = p.shape
+    assert p.dtype == d.dtype == dd.dtype == torch.bfloat16 and tuple(weight.shape[:2]) == (64, 64)
+    ev0 = TIMER.start() if TIMER is not None else None
+    check(lib().nvq_pw_bn_backward(ptr(dy), dy.shape[-1], is_bf16(dy), ptr(p), p.shape[-1], ptr(d), d.shape[-1], N,
+                                   group_images, H, W, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(training),
+                                   ptr(weight.contiguous()), ptr(dd), dd.shape[-1], ptr(dgamma), ptr(dbeta), ptr(dweight),
+                                   ptr(ws), ws.numel() * 4, stream()), "nvq_pw_bn_backward")
+    if ev0 is not None:
+        npx = N * H * W
+        TIMER.stop(ev0, "pw_bn_bwd_kernel", 2.0 * npx * 64 * 64 * 2,
+                   npx * 64 * (2.0 * 2 + (2 if is_bf16(dy) else 4) * 2 + 2), f"n{N} 64->64 {'h' if is_bf16(dy) else 'f'}")
 
 
 # ----------------------------------------------------------------------------- motion

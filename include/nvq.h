@@ -154,6 +154,18 @@ size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape *
 int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);
 size_t nvq_sizeof_wgrad_desc(void);
 
+/* Backward of  pointwise 1x1 conv (no bias) -> BatchNorm2d -> ReLU  of a DepthwiseSeparableConv (efficient_layers.py:49-66) in
+ * the bf16 mode, 64 channels in and out: what nvq_bn_relu_backward + nvq_conv_forward (transposed pack) + nvq_conv_wgrad do
+ * in three passes, after the BatchNorm sums in ONE pass over the tensors (dp = the BatchNorm-input gradient is formed in LDS
+ * and never stored).  dy [N,H,W,dy_ld]: gradient w.r.t. relu(bn(p)), fp32 or bf16; p: the conv output = BatchNorm input, d: the
+ * conv input (both bf16); groups of `group_images` images have their own statistics mean / invstd [G][64];
+ * weight [64 co][64 ci] fp32.  Outputs: dd (bf16) = gradient w.r.t. d; dgamma, dbeta [64]; dweight [64][64] (all overwritten).
+ * workspace: nvq_wgrad_workspace_bytes() is enough. */
+int nvq_pw_bn_backward(const float* dy, int dy_ld, int dy_bf16, const float* p, int p_ld, const float* d, int d_ld,
+                       int N, int group_images, int H, int W, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int training, const float* weight, float* dd, int dd_ld,
+                       float* dgamma, float* dbeta, float* dweight, float* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ feature extractor
  * FeatureExtractor.head, super_resolution.py:40-43: relu(conv3x3(frame; W[F,Cin,3,3], b)).
  * frames: fp32 NCHW clip (B,T,Cin,H,W) contiguous.  Output image index = slot*B + b

@@ -682,6 +682,56 @@ def test_extractor_kernels_with_bf16_stored_tensors(K):
     assert rel(dg, gamma.grad) < 5e-5 and rel(db, beta.grad) < 5e-5
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("dy16", [True, False])
+@pytest.mark.parametrize("B,G,H,W", [(2, 3, 9, 14), (1, 2, 16, 40), (3, 1, 5, 7)])
+def test_pointwise_batchnorm_backward_in_one_pass(K, training, dy16, B, G, H, W):
+    """nvq_pw_bn_backward: ReLU + BatchNorm backward, the 1x1 conv's input gradient and its weight gradient from one staged
+    tile (dp never stored) against (a) the three-launch path it replaces and (b) autograd of the reference ops
+    (efficient_layers.py:49-66); groups whose pixel count is not a multiple of the 128-pixel tile, fp32 / bf16 dy, train / eval."""
+    C, N = 64, B * G
+    d = bf(rnd(N, C, H, W, seed=1))
+    w = bf(rnd(C, C, 1, 1, scale=0.15, seed=2))
+    gamma, beta = 1 + 0.2 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    dy = bf(rnd(N, C, H, W, seed=5))
+    dg, wg, gg, bg = d.clone().requires_grad_(), w.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    p_ref = F.conv2d(dg, wg)
+    p16 = bf(p_ref.detach())                                   # what the forward stored: bf16
+    rm, rv = 0.1 * rnd(C, seed=6), 1 + 0.3 * rnd(C, seed=7).abs()
+    # autograd reference on the bf16-stored conv output (per frame group statistics)
+    pl = p16.clone().requires_grad_()
+    outs = [F.relu(F.batch_norm(pl[g * B:(g + 1) * B], rm.clone(), rv.clone(), gg, bg, training, 0.1, 1e-5)) for g in range(G)]
+    torch.cat(outs, 0).backward(dy)
+    dp_ref = pl.grad
+    dd_ref = F.conv_transpose2d(bf(dp_ref), w)                  # dd = dp W (dp as the kernels see it: bf16)
+    dw_ref = torch.einsum("nohw,nihw->oi", bf(dp_ref), d)
+    pb, db_ = to_nhwc_bf16(p16), to_nhwc_bf16(d)
+    dyb = to_nhwc_bf16(dy) if dy16 else to_nhwc(dy)
+    mean, invstd = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+    ws = ws_tensor(K)
+    if training:
+        K.bn_stats(pb, B, list(range(G)), mean, invstd, None, None, ws)
+    else:
+        K.bn_eval_stats(rm.cuda(), rv.cuda(), G, mean, invstd)
+    dd = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    dga, dbe, dwt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, C, 1, 1, device="cuda")
+    K.pw_bn_backward(dyb, pb, db_, B, mean, invstd, gamma.cuda(), beta.cuda(), training, w.cuda(), dd, dga, dbe, dwt, ws)
+    # (a) the three launches
+    dp3 = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    dga3, dbe3 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    K.bn_relu_backward(dyb, pb, B, mean, invstd, gamma.cuda(), beta.cuda(), training, dp3, dga3, dbe3, ws)
+    dw3 = torch.empty(C, C, 1, 1, device="cuda")
+    K.conv_wgrad(K.Sl(db_), C, K.Sl(dp3), dw3, None, ws, 1, math=K.MATH_BF16)
+    dd3 = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.conv_forward(K.Sl(dp3), K.conv_pack(w.cuda(), True, C, C, math=K.MATH_BF16), None, K.Sl(dd3), 1, math=K.MATH_BF16)
+    assert torch.equal(dga, dga3) and torch.equal(dbe, dbe3)
+    assert rel(dd.float(), dd3.float()) < 1e-2 and rel(dwt, dw3) < 2e-5
+    # (b) autograd
+    assert rel(from_nhwc(dd.float()), dd_ref) < 1.5e-2          # dp and dd each rounded to bf16 once
+    assert rel(dwt.reshape(C, C), dw_ref) < 1e-2
+    assert rel(dga, gg.grad) < 1e-4 and rel(dbe, bg.grad) < 1e-4
+
+
 @pytest.mark.parametrize("C,N,H,W", [(64, 2, 11, 37), (128, 1, 8, 32), (64, 3, 17, 70)])
 def test_dwconv_bf16_full_line_kernels(K, C, N, H, W):
     """The 64-channel bf16 depthwise kernels (forward, flipped = input gradient, weight gradient), ragged tiles,
