@@ -1099,6 +1099,17 @@ int bn_backward_sums(const float* dy, int dy_ld, const float* x, int x_ld, int C
     return check_launch("bn_bwd_finalize");
 }
 
+// part[g][blk][2C] = {sum, sum of squares} -> mean / invstd per group; the groups are folded into the running statistics in
+// `order_host` (identity when null).  Shared by nvq_bn_stats and the fused forward kernel (dwpw_fwd.hip).
+int bn_finalize_launch(const float* part, int nblk, int C, int G, long group_pix, float eps, float momentum,
+                       const int* order_host, float* mean, float* invstd, float* rmean, float* rvar, hipStream_t s) {
+    GroupOrder order;
+    for (int i = 0; i < NVQ_MAX_T; ++i) order.g[i] = i < G ? (order_host ? order_host[i] : i) : 0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, part, nblk, C, G, group_pix, eps, momentum, order, mean,
+                       invstd, rmean, rvar);
+    return check_launch("bn_finalize");
+}
+
 static int blocks_for(long npix, int C) {
     const int npl = 256 / (C >> 2);
     int nb = ceil_div(npix, (long)npl * 16);
@@ -1287,11 +1298,8 @@ int nvq_bn_stats(const float* x, int x_ld, int C, int N, int group_images, int H
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, G), dim3(256), 0, s, x, x_ld, C, group_pix, x_bf16, workspace);
     int rc = check_launch("bn_stats");
     if (rc) return rc;
-    GroupOrder order;
-    for (int i = 0; i < NVQ_MAX_T; ++i) order.g[i] = i < G ? (order_host ? order_host[i] : i) : 0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, group_pix,
-                       eps, momentum, order, mean, invstd, running_mean, running_var);
-    return check_launch("bn_finalize");
+    return bn_finalize_launch(workspace, nblk, C, G, group_pix, eps, momentum, order_host, mean, invstd, running_mean,
+                              running_var, s);
 }
 
 int nvq_bn_eval_stats(const float* running_mean, const float* running_var, int C, int G, float eps,

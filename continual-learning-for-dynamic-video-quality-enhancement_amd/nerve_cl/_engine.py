@@ -102,18 +102,27 @@ def _extract(P: Dict[str, torch.Tensor], frames: torch.Tensor, slots, F: int, tr
     cur, cur_bn = feat0, None         # cur_bn: BatchNorm + ReLU still to be applied to `cur` (fused into the consumer)
     sv.dw_in = []                     # (tensor, bn) the depthwise conv of layer k was fed with
     fuse_bn = K.dwconv_bn_fusable(feat0, F)
+    fused_fwd = fuse_bn and F == 64 and math == K.MATH_BF16 and os.environ.get("NVQ_FUSED_DWPW", "1") != "0"
     for k in range(3):
         pre = f"feature_extractor.body.{k}."
         d = _new(dev, NI, H, W, F, dtype=act_dtype)
-        K.dwconv_forward(cur, P[pre + "depthwise.weight"], d, bn=cur_bn)
-        sv.dw_in.append((cur, cur_bn))
         p = _new(dev, NI, H, W, F, dtype=act_dtype)
-        wp = K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math)
-        K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
         mean, invstd = _new(dev, T, F), _new(dev, T, F)
+        order = [slots.index(t) for t in range(T)]
+        if fused_fwd:
+            # depthwise -> pointwise -> BatchNorm sums in one pass over the tensors (nvq_dwpw_forward)
+            K.dwpw_forward(cur, cur_bn, P[pre + "depthwise.weight"], P[pre + "pointwise.weight"], d, p, B,
+                           order if training else None, mean, invstd, P[pre + "bn.running_mean"],
+                           P[pre + "bn.running_var"], ws, BN_EPS, BN_MOM)
+        else:
+            K.dwconv_forward(cur, P[pre + "depthwise.weight"], d, bn=cur_bn)
+            wp = K.conv_pack(P[pre + "pointwise.weight"], False, F, math=math)
+            K.conv_forward(Sl(d), wp, None, Sl(p), 1, math=math)
+            if training:
+                K.bn_stats(p, B, order, mean, invstd, P[pre + "bn.running_mean"], P[pre + "bn.running_var"], ws, BN_EPS,
+                           BN_MOM)
+        sv.dw_in.append((cur, cur_bn))
         if training:
-            K.bn_stats(p, B, [slots.index(t) for t in range(T)], mean, invstd,
-                       P[pre + "bn.running_mean"], P[pre + "bn.running_var"], ws, BN_EPS, BN_MOM)
             P[pre + "bn.num_batches_tracked"].add_(T)
         else:
             K.bn_eval_stats(P[pre + "bn.running_mean"], P[pre + "bn.running_var"], T, mean, invstd, BN_EPS)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
+    "nvq_dwpw_forward": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
@@ -621,6 +622,26 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
                                      ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), is_bf16(dy),
                                      is_bf16(x), is_bf16(dx), stream()),
           "nvq_bn_relu_backward")
+
+
+def dwpw_forward(x: torch.Tensor, bn, dw_weight: torch.Tensor, pw_weight: torch.Tensor, d: torch.Tensor, p: torch.Tensor,
+                 group_images: int, order: Optional[Sequence[int]], mean, invstd, rmean, rvar, ws, eps=1e-5,
+                 momentum=0.1) -> None:
+    """depthwise 3x3 -> pointwise 1x1 -> BatchNorm statistics in one pass (bf16 mode, 64 channels): see nvq_dwpw_forward.
+    bn = (mean, invstd, gamma, beta, group_images) of the previous layer or None; order None: no statistics (eval mode)."""
+    N, H, W, ld = x.shape
+    assert x.dtype == d.dtype == p.dtype == torch.bfloat16 and tuple(pw_weight.shape[:2]) == (64, 64)
+    b = _bn_input(bn)
+    stats = order is not None
+    ev0 = TIMER.start() if TIMER is not None else None
+    check(lib().nvq_dwpw_forward(ptr(x), ld, C.byref(b) if b is not None else None, ptr(dw_weight.contiguous()),
+                                 ptr(pw_weight.contiguous()), ptr(d), d.shape[-1], ptr(p), p.shape[-1], N, group_images, H, W,
+                                 int(stats), eps, momentum, int_array(order) if stats else None, ptr(mean) if stats else None,
+                                 ptr(invstd) if stats else None, ptr(rmean) if stats else None, ptr(rvar) if stats else None,
+                                 ptr(ws), ws.numel() * 4, stream()), "nvq_dwpw_forward")
+    if ev0 is not None:
+        npx = N * H * W
+        TIMER.stop(ev0, "dwpw_fwd_kernel", 2.0 * npx * 64 * (64 + 9), npx * 64 * 2.0 * 3, f"n{N} 64->64")
 
 
 def pw_bn_backward(dy: torch.Tensor, p: torch.Tensor, d: torch.Tensor, group_images: int, mean, invstd, gamma, beta,

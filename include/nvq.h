@@ -212,6 +212,19 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
                      int N, int H, int W, float* dweight, float* workspace,
                      size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16,
                      const nvq_bn_input* bn, void* stream);
+/* Forward of  depthwise 3x3 -> pointwise 1x1 (no bias) -> BatchNorm2d statistics  of a DepthwiseSeparableConv
+ * (efficient_layers.py:49-66) in the bf16 mode, 64 channels: what nvq_dwconv_forward + nvq_conv_forward (1x1) + nvq_bn_stats
+ * do in three launches (five tensor passes), in one pass x -> d, p.  in [N,H,W,in_ld] bf16; bn != NULL: x := relu(bn(x)) is
+ * applied while the halo is staged (the previous layer's BatchNorm + ReLU, as in nvq_dwconv_forward; its group_images must be
+ * `group_images`); dw_weight [64][3][3], pw_weight [64 co][64 ci] fp32.  Outputs (bf16, overwritten): d = the depthwise
+ * result (the backward's operand), p = the pointwise result = BatchNorm input.  stats != 0: the batch statistics of p (of
+ * the stored bf16 values) per group of `group_images` images go to mean / invstd [G][64] and are folded into running_mean /
+ * running_var (either may be NULL) in the order order_host[0..G-1] (host array; NULL: 0..G-1), exactly as nvq_bn_stats does; workspace >= 512*128 floats.
+ * stats == 0: p and d only (eval mode: the caller takes mean / invstd from nvq_bn_eval_stats). */
+int nvq_dwpw_forward(const float* in, int in_ld, const nvq_bn_input* bn, const float* dw_weight, const float* pw_weight,
+                     float* d, int d_ld, float* p, int p_ld, int N, int group_images, int H, int W, int stats, float eps,
+                     float momentum, const int* order_host, float* mean, float* invstd, float* running_mean, float* running_var,
+                     float* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm2d, efficient_layers.py:59,65.  The N images form G = N/group_images groups
  * (one per feature-extractor call); statistics are per (group, channel) over

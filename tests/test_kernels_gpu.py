@@ -732,6 +732,55 @@ def test_pointwise_batchnorm_backward_in_one_pass(K, training, dy16, B, G, H, W)
     assert rel(dga, gg.grad) < 1e-4 and rel(dbe, bg.grad) < 1e-4
 
 
+@pytest.mark.parametrize("with_bn", [False, True])
+@pytest.mark.parametrize("stats", [True, False])
+@pytest.mark.parametrize("B,G,H,W", [(2, 3, 9, 14), (1, 2, 16, 64), (3, 1, 5, 7), (9, 3, 17, 40)])
+def test_depthwise_pointwise_batchnorm_sums_forward_in_one_pass(K, with_bn, stats, B, G, H, W):
+    """nvq_dwpw_forward: depthwise 3x3 -> pointwise 1x1 -> BatchNorm statistics from one staged halo tile against (a) the three
+    launches it replaces and (b) the reference ops (efficient_layers.py:49-66); ragged tiles, more tiles than workgroups per
+    group (B = 9: persistent loop), with / without the previous layer's BatchNorm + ReLU on the input, with / without sums."""
+    C, N = 64, B * G
+    x = bf(rnd(N, C, H, W, seed=1) * 1.5 + 0.2)
+    wd, wp = rnd(C, 1, 3, 3, seed=2), bf(rnd(C, C, 1, 1, scale=0.15, seed=3))
+    xb = to_nhwc_bf16(x)
+    ws = ws_tensor(K)
+    bn, xin = None, x
+    if with_bn:
+        gamma, beta = (1 + 0.2 * rnd(C, seed=4)).cuda(), (0.1 * rnd(C, seed=5)).cuda()
+        m0, i0 = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+        K.bn_stats(xb, B, list(range(G)), m0, i0, None, None, ws)
+        bn = (m0, i0, gamma, beta, B)
+        r = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+        K.bn_apply_relu(xb, B, m0, i0, gamma, beta, None, K.Sl(r), N)
+        xin = from_nhwc(r.float()).cpu()                        # what the staged tile holds
+    order = list(range(G))[::-1]
+    rm, rv = (0.1 * rnd(C, seed=6)).cuda(), (1 + 0.3 * rnd(C, seed=7).abs()).cuda()
+    rm3, rv3 = rm.clone(), rv.clone()
+    d = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    p = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    mean, invstd = torch.zeros(G, C, device="cuda"), torch.zeros(G, C, device="cuda")
+    K.dwpw_forward(xb, bn, wd.cuda(), wp.cuda(), d, p, B, order if stats else None, mean, invstd, rm, rv, ws)
+    # (a) the three launches
+    d3 = torch.empty_like(d)
+    K.dwconv_forward(xb, wd.cuda(), d3, bn=bn)
+    p3 = torch.empty_like(p)
+    K.conv_forward(K.Sl(d3), K.conv_pack(wp.cuda(), False, C, math=K.MATH_BF16), None, K.Sl(p3), 1, math=K.MATH_BF16)
+    assert torch.equal(d, d3)
+    assert rel(p.float(), p3.float()) < 2e-3                    # same operands; summation order / one bf16 rounding apart
+    if stats:
+        mean3, invstd3 = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+        K.bn_stats(p, B, order, mean3, invstd3, rm3, rv3, ws)
+        assert (mean - mean3).abs().max() < 1e-5 * (1 + mean3.abs().max()) and rel(invstd, invstd3) < 1e-5
+        assert rel(rm, rm3) < 1e-5 and rel(rv, rv3) < 1e-5
+    else:
+        assert not mean.any() and not invstd.any() and torch.equal(rm, rm3)
+    # (b) the reference ops on the same bf16 operands
+    d_ref = F.conv2d(xin, wd, None, padding=1, groups=C)
+    assert rel(from_nhwc(d.float()).cpu(), d_ref) < 5e-3
+    p_ref = F.conv2d(bf(d_ref), wp)
+    assert rel(from_nhwc(p.float()).cpu(), p_ref) < 8e-3
+
+
 @pytest.mark.parametrize("C,N,H,W", [(64, 2, 11, 37), (128, 1, 8, 32), (64, 3, 17, 70)])
 def test_dwconv_bf16_full_line_kernels(K, C, N, H, W):
     """The 64-channel bf16 depthwise kernels (forward, flipped = input gradient, weight gradient), ragged tiles,
