@@ -712,9 +712,9 @@ __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __re
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const float4 vv = dw_lds4(xs, r * DT_HW + x + b, c4);
-                if (r < DT_H) { const float4 ww = w[b]; a0.x += vv.x * ww.x; a0.y += vv.y * ww.y; a0.z += vv.z * ww.z; a0.w += vv.w * ww.w; }
-                if (r >= 1 && r <= DT_H) { const float4 ww = w[3 + b]; a1.x += vv.x * ww.x; a1.y += vv.y * ww.y; a1.z += vv.z * ww.z; a1.w += vv.w * ww.w; }
-                if (r >= 2) { const float4 ww = w[6 + b]; a2.x += vv.x * ww.x; a2.y += vv.y * ww.y; a2.z += vv.z * ww.z; a2.w += vv.w * ww.w; }
+                if (r < DT_H) { const float4 ww = w[b]; a0.x = __builtin_fmaf(vv.x, ww.x, a0.x); a0.y = __builtin_fmaf(vv.y, ww.y, a0.y); a0.z = __builtin_fmaf(vv.z, ww.z, a0.z); a0.w = __builtin_fmaf(vv.w, ww.w, a0.w); }
+                if (r >= 1 && r <= DT_H) { const float4 ww = w[3 + b]; a1.x = __builtin_fmaf(vv.x, ww.x, a1.x); a1.y = __builtin_fmaf(vv.y, ww.y, a1.y); a1.z = __builtin_fmaf(vv.z, ww.z, a1.z); a1.w = __builtin_fmaf(vv.w, ww.w, a1.w); }
+                if (r >= 2) { const float4 ww = w[6 + b]; a2.x = __builtin_fmaf(vv.x, ww.x, a2.x); a2.y = __builtin_fmaf(vv.y, ww.y, a2.y); a2.z = __builtin_fmaf(vv.z, ww.z, a2.z); a2.w = __builtin_fmaf(vv.w, ww.w, a2.w); }
             }
             if (r >= 2) {
                 const int y = r - 2;

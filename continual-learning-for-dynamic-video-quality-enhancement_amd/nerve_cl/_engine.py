@@ -449,8 +449,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     for k in (2, 1, 0):
         pre = f"feature_extractor.body.{k}."
         dd = _new(dev, NI, H, W, F, dtype=act_dtype)
-        if (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F == 64 and sv.pws[k].dtype == torch.bfloat16
-                and sv.dws[k].dtype == torch.bfloat16 and os.environ.get("NVQ_FUSED_PW_BWD", "1") != "0"):
+        fused_bwd = (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F == 64 and sv.pws[k].dtype == torch.bfloat16
+                     and sv.dws[k].dtype == torch.bfloat16)
+        if fused_bwd and os.environ.get("NVQ_FUSED_PW_BWD", "1") != "0":
             # BatchNorm backward + the pointwise conv's input and weight gradients in one pass behind the BatchNorm sums: dp is
             # formed in LDS and never stored (nvq_pw_bn_backward)
             K.pw_bn_backward(dcur, sv.pws[k], sv.dws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
@@ -463,6 +464,14 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
             K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin, xin_bn = sv.dw_in[k]
+        if fused_bwd and k > 0 and xin.dtype == torch.bfloat16 and os.environ.get("NVQ_FUSED_DW_BWD", "1") != "0":
+            # the depthwise conv's input gradient and weight gradient from one staged tile (nvq_dwconv_backward).  Not for the
+            # first layer: with the skip-path add and the head's ReLU mask in its epilogue the one-tile kernel takes as long as
+            # the two launches below (2.53 vs 2.54 ms: the epilogue operands are loaded where they are used, by 8 waves per CU)
+            dx = _new(dev, NI, H, W, F, dtype=act_dtype)
+            K.dwconv_backward(xin, xin_bn, dd, P[pre + "depthwise.weight"], dx, G[pre + "depthwise.weight"], ws)
+            dcur = dx
+            continue
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws, bn=xin_bn)
         if k == 0 and sv.img8 is not None:
             # dx + skip path, ReLU-masked by the head features: the gradient of the head conv, as bf16

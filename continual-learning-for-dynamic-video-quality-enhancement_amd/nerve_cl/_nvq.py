@@ -91,6 +91,7 @@ SIGNATURES = {
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
+    "nvq_dwconv_backward": (ci, [vp, ci, vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp, vp, sz, vp]),
     "nvq_dwpw_forward": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
@@ -622,6 +623,24 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
                                      ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4, int(accumulate), is_bf16(dy),
                                      is_bf16(x), is_bf16(dx), stream()),
           "nvq_bn_relu_backward")
+
+
+def dwconv_backward(x: torch.Tensor, bn, dy: torch.Tensor, weight: torch.Tensor, dx: torch.Tensor, dweight, ws,
+                    add: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> None:
+    """Input and weight gradient of a 64-channel depthwise 3x3 conv from one staged tile (bf16 mode): see nvq_dwconv_backward.
+    bn = (mean, invstd, gamma, beta, group_images): the conv was fed relu(bn(x)); add (fp32) / mask (bf16): dx = (dx + add)
+    where mask > 0."""
+    N, H, W, ld = x.shape
+    assert x.dtype == dy.dtype == dx.dtype == torch.bfloat16 and weight.shape[0] == 64
+    b = _bn_input(bn)
+    e = None
+    if add is not None or mask is not None:
+        e = DwEpilogue()
+        e.add, e.add_ld = ptr(add), add.shape[-1] if add is not None else 0
+        e.mask, e.mask_ld, e.mask_bf16 = ptr(mask), mask.shape[-1] if mask is not None else 0, is_bf16(mask)
+    check(lib().nvq_dwconv_backward(ptr(x), ld, C.byref(b) if b is not None else None, ptr(dy), dy.shape[-1],
+                                    ptr(weight.contiguous()), ptr(dx), dx.shape[-1], C.byref(e) if e is not None else None,
+                                    N, H, W, ptr(dweight), ptr(ws), ws.numel() * 4, stream()), "nvq_dwconv_backward")
 
 
 def dwpw_forward(x: torch.Tensor, bn, dw_weight: torch.Tensor, pw_weight: torch.Tensor, d: torch.Tensor, p: torch.Tensor,

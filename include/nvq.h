@@ -212,6 +212,15 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
                      int N, int H, int W, float* dweight, float* workspace,
                      size_t workspace_bytes, int accumulate, int x_bf16, int dy_bf16,
                      const nvq_bn_input* bn, void* stream);
+/* Backward of the depthwise 3x3 conv of a DepthwiseSeparableConv (efficient_layers.py:49-66) in the bf16 mode, 64 channels:
+ * what nvq_dwconv_wgrad + nvq_dwconv_forward(flip = 1) do in two launches, from one staged tile (x, dy -> dx; dy read once).
+ * x [N,H,W,x_ld] bf16: the conv's input; bn != NULL: the input was relu(bn(x)) (evaluated while x is staged, as in
+ * nvq_dwconv_wgrad); dy: gradient w.r.t. the conv output, bf16; weight [64][3][3] fp32.  Outputs: dx (bf16, overwritten) =
+ * gradient w.r.t. the conv input, through the optional epilogue dx = (dx + add) where mask > 0 (add fp32, mask bf16);
+ * dweight [64][3][3] (overwritten).  workspace >= 512*576 floats. */
+int nvq_dwconv_backward(const float* x, int x_ld, const nvq_bn_input* bn, const float* dy, int dy_ld, const float* weight,
+                        float* dx, int dx_ld, const nvq_dw_epilogue* epi, int N, int H, int W, float* dweight,
+                        float* workspace, size_t workspace_bytes, void* stream);
 /* Forward of  depthwise 3x3 -> pointwise 1x1 (no bias) -> BatchNorm2d statistics  of a DepthwiseSeparableConv
  * (efficient_layers.py:49-66) in the bf16 mode, 64 channels: what nvq_dwconv_forward + nvq_conv_forward (1x1) + nvq_bn_stats
  * do in three launches (five tensor passes), in one pass x -> d, p.  in [N,H,W,in_ld] bf16; bn != NULL: x := relu(bn(x)) is

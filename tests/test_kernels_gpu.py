@@ -781,6 +781,51 @@ def test_depthwise_pointwise_batchnorm_sums_forward_in_one_pass(K, with_bn, stat
     assert rel(from_nhwc(p.float()).cpu(), p_ref) < 8e-3
 
 
+@pytest.mark.parametrize("with_bn", [False, True])
+@pytest.mark.parametrize("with_epi", [False, True])
+@pytest.mark.parametrize("B,G,H,W", [(2, 3, 9, 14), (1, 2, 16, 64), (3, 1, 5, 7), (9, 3, 17, 40)])
+def test_depthwise_backward_input_and_weight_gradient_from_one_tile(K, with_bn, with_epi, B, G, H, W):
+    """nvq_dwconv_backward against (a) the two launches it replaces (weight gradient; flipped conv with the add / mask epilogue)
+    and (b) autograd of the reference's nn.Conv2d(groups = C) (efficient_layers.py:49-66); ragged tiles, persistent loop (B = 9),
+    with / without the previous layer's BatchNorm + ReLU on the conv input."""
+    C, N = 64, B * G
+    x = bf(rnd(N, C, H, W, seed=1) * 1.5 + 0.2)
+    dy = bf(rnd(N, C, H, W, seed=2))
+    wd = rnd(C, 1, 3, 3, seed=3)
+    xb, dyb = to_nhwc_bf16(x), to_nhwc_bf16(dy)
+    ws = ws_tensor(K)
+    bn, xin = None, x
+    if with_bn:
+        gamma, beta = (1 + 0.2 * rnd(C, seed=4)).cuda(), (0.1 * rnd(C, seed=5)).cuda()
+        m0, i0 = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+        K.bn_stats(xb, B, list(range(G)), m0, i0, None, None, ws)
+        bn = (m0, i0, gamma, beta, B)
+        r = torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+        K.bn_apply_relu(xb, B, m0, i0, gamma, beta, None, K.Sl(r), N)
+        xin = from_nhwc(r.float())                              # what the conv was fed
+    add = to_nhwc(rnd(N, C, H, W, seed=6)) if with_epi else None
+    mask_c = bf(rnd(N, C, H, W, seed=7)).clamp_min(0) if with_epi else None
+    mask = to_nhwc_bf16(mask_c) if with_epi else None
+    dx = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    dw = torch.zeros(C, 1, 3, 3, device="cuda")
+    K.dwconv_backward(xb, bn, dyb, wd.cuda(), dx, dw, ws, add=add, mask=mask)
+    # (a) the two launches
+    dw2 = torch.empty(C, 1, 3, 3, device="cuda")
+    K.dwconv_wgrad(xb, dyb, dw2, ws, bn=bn)
+    dx2 = torch.empty_like(dx)
+    K.dwconv_forward(dyb, wd.cuda(), dx2, flip=True, add=add, mask=mask)
+    assert torch.equal(dx, dx2)
+    assert rel(dw, dw2) < 2e-5
+    # (b) autograd
+    xg, wg = xin.clone().requires_grad_(), wd.clone().requires_grad_()
+    F.conv2d(xg, wg, None, padding=1, groups=C).backward(dy)
+    want = xg.grad
+    if with_epi:
+        want = (want + from_nhwc(add)) * (mask_c > 0)
+    assert rel(from_nhwc(dx.float()), want) < 5e-3             # one bf16 rounding of the result
+    assert rel(dw, wg.grad) < TOL
+
+
 @pytest.mark.parametrize("C,N,H,W", [(64, 2, 11, 37), (128, 1, 8, 32), (64, 3, 17, 70)])
 def test_dwconv_bf16_full_line_kernels(K, C, N, H, W):
     """The 64-channel bf16 depthwise kernels (forward, flipped = input gradient, weight gradient), ragged tiles,
