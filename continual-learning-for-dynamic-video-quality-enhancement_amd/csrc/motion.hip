@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
                                                            float* __restrict__ dfeat, int dfeat_ld,
                                                            float* __restrict__ dflow, int dflow_ld,
                                                            float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix,
-                                                           int feat_bf16, int dout_bf16) {
+                                                           int feat_bf16, int dout_bf16, int* __restrict__ far_flag) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     const long pix = gid >> 4;
     if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
     const int ox = g.x0 - x, oy = g.y0 - y;
     const bool any = g.vnw || g.vne || g.vsw || g.vse;
     const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
-    const bool scatter = any && !near;
+    // far_flag != NULL (overwrite mode: dfeat is not initialised yet): a far source is only flagged here and scattered by
+    // warp_bwd_far_kernel behind the gather pass
+    const bool scatter = any && !near && far_flag == nullptr;
+    if (any && !near && far_flag != nullptr && c4 == 0) *far_flag = 1;
     float gix = 0.f, giy = 0.f;
     for (int ch = 4 * c4; ch < C; ch += 64) {
         const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
@@ -390,6 +393,40 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
     }
 }
 
+// Overwrite mode, behind the gather pass: the sources the window cannot reach (|flow| >= 4 px), scattered with atomics as the
+// src pass does in the accumulate mode.  Leaves at once when the src pass flagged none (the usual case).
+__global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
+                                                           const float* __restrict__ flow, int flow_ld, int C, int H, int W,
+                                                           float* __restrict__ dfeat, int dfeat_ld, long npix, int dout_bf16,
+                                                           const int* __restrict__ far_flag) {
+    if (*far_flag == 0) return;
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    const long pix = gid >> 4;
+    if (pix >= npix) return;
+    const int c4 = gid & 15;
+    const long rowi = idiv(pix, W, npix);
+    const int x = (int)(pix - rowi * W);
+    const int y = (int)(rowi - idiv(rowi, H, npix) * H);
+    const long img = pix - ((long)y * W + x);
+    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+    const int ox = g.x0 - x, oy = g.y0 - y;
+    const bool any = g.vnw || g.vne || g.vsw || g.vse;
+    const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
+    if (!any || near) return;
+    for (int ch = 4 * c4; ch < C; ch += 64) {
+        const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
+        auto corner = [&](bool valid, long o, float wgt) {
+            if (!valid) return;
+            float* db = dfeat + o * dfeat_ld + ch;
+            atomicAdd(db, go.x * wgt); atomicAdd(db + 1, go.y * wgt); atomicAdd(db + 2, go.z * wgt); atomicAdd(db + 3, go.w * wgt);
+        };
+        corner(g.vnw, img + (long)g.y0 * W + g.x0, g.wnw);
+        corner(g.vne, img + (long)g.y0 * W + g.x0 + 1, g.wne);
+        corner(g.vsw, img + (long)(g.y0 + 1) * W + g.x0, g.wsw);
+        corner(g.vse, img + (long)(g.y0 + 1) * W + g.x0 + 1, g.wse);
+    }
+}
+
 // grid = destination tiles of 8 x 32 pixels.  Phase 1: thread = one destination pixel, scans its 9x9 window of records and
 // lists the contributing sources (window index, weight) in LDS.  Phase 2: 16 lanes per pixel (one float4 of channels
 // each, so a pixel's 64 channels are one coalesced 256-byte access) walk the lists and add into dfeat.
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                                                               const float4* __restrict__ rec_w,
                                                               const int* __restrict__ rec_code, int C, int H, int W,
                                                               int tilesX, int tilesY, float* __restrict__ dfeat,
-                                                              int dfeat_ld, int dout_bf16) {
+                                                              int dfeat_ld, int dout_bf16, int overwrite) {
     __shared__ float4 lw[WG_HH * WG_HW];
     __shared__ int lc[WG_HH * WG_HW];
     __shared__ int hit_n[WG_TH * WG_TW];
@@ -418,45 +455,43 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
         lw[i] = ok ? rec_w[pp] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    {   // ---- phase 1
-        const int ly = threadIdx.x / WG_TW, lx = threadIdx.x % WG_TW;
-        const int qy = ty * WG_TH + ly, qx = tx * WG_TW + lx;
+    // window scan of destination pixel (ly, lx): calls hit(k, sy, sx, weight) for its k-th contributing source, in a fixed order
+    auto scan = [&](int ly, int lx, auto&& hit) {
         int cnt = 0;
-        if (qy < H && qx < W) {
-            for (int sy = -WG_R; sy <= WG_R; ++sy)
-                for (int sx = -WG_R; sx <= WG_R; ++sx) {
-                    const int hi = (ly + WG_R + sy) * WG_HW + lx + WG_R + sx;
-                    const int code = lc[hi];
-                    if (code < 0) continue;
-                    const int a = -sy - ((code >> 4) - WG_R), b = -sx - ((code & 15) - WG_R);   // q - p - offset(p)
-                    if ((unsigned)a > 1u || (unsigned)b > 1u) continue;
-                    const float4 w4 = lw[hi];
-                    const float wgt = a == 0 ? (b == 0 ? w4.x : w4.y) : (b == 0 ? w4.z : w4.w);
-                    if (wgt == 0.f) continue;
-                    if (cnt < WG_MAXHIT) {
-                        hit_p[threadIdx.x * WG_MAXHIT + cnt] = ((sy + WG_R) << 4) | (sx + WG_R);
-                        hit_w[threadIdx.x * WG_MAXHIT + cnt] = wgt;
-                        ++cnt;
-                    } else {                                  // overflow: apply directly (still no atomics: q is ours)
-                        const size_t so = ((size_t)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff;
-                        float* dst = dfeat + ((long)(n * H + qy) * W + qx) * dfeat_ld;
-                        for (int ch = 0; ch < C; ch += 4) {   // C % 4 == 0
-                            const float4 v = ldx4(dout, so + ch, dout_bf16);
-                            dst[ch] += wgt * v.x; dst[ch + 1] += wgt * v.y; dst[ch + 2] += wgt * v.z; dst[ch + 3] += wgt * v.w;
-                        }
-                    }
-                }
-        }
-        hit_n[threadIdx.x] = cnt;
-    }
+        for (int sy = -WG_R; sy <= WG_R; ++sy)
+            for (int sx = -WG_R; sx <= WG_R; ++sx) {
+                const int hi = (ly + WG_R + sy) * WG_HW + lx + WG_R + sx;
+                const int code = lc[hi];
+                if (code < 0) continue;
+                const int a = -sy - ((code >> 4) - WG_R), b = -sx - ((code & 15) - WG_R);   // q - p - offset(p)
+                if ((unsigned)a > 1u || (unsigned)b > 1u) continue;
+                const float4 w4 = lw[hi];
+                const float wgt = a == 0 ? (b == 0 ? w4.x : w4.y) : (b == 0 ? w4.z : w4.w);
+                if (wgt == 0.f) continue;
+                hit(cnt, sy, sx, wgt);
+                ++cnt;
+            }
+        return cnt;
+    };
+    const int ly1 = threadIdx.x / WG_TW, lx1 = threadIdx.x % WG_TW;
+    const int qy1 = ty * WG_TH + ly1, qx1 = tx * WG_TW + lx1;
+    int total1 = 0;
+    if (qy1 < H && qx1 < W)                                   // ---- phase 1: list the first WG_MAXHIT sources
+        total1 = scan(ly1, lx1, [&](int k, int sy, int sx, float wgt) {
+            if (k < WG_MAXHIT) {
+                hit_p[threadIdx.x * WG_MAXHIT + k] = ((sy + WG_R) << 4) | (sx + WG_R);
+                hit_w[threadIdx.x * WG_MAXHIT + k] = wgt;
+            }
+        });
+    hit_n[threadIdx.x] = total1 < WG_MAXHIT ? total1 : WG_MAXHIT;
     __syncthreads();
     // ---- phase 2
     const int c4 = threadIdx.x & 15;
     for (int qi = threadIdx.x >> 4; qi < WG_TH * WG_TW; qi += 16) {
         const int cnt = hit_n[qi];
-        if (cnt == 0) continue;                               // (uniform over the 16 lanes of the pixel)
         const int ly = qi / WG_TW, lx = qi % WG_TW;
         const int qy = ty * WG_TH + ly, qx = tx * WG_TW + lx;
+        if ((cnt == 0 && !overwrite) || qy >= H || qx >= W) continue;   // (uniform over the 16 lanes of the pixel)
         const long qpix = (long)(n * H + qy) * W + qx;
         for (int ch = 4 * c4; ch < C; ch += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -468,9 +503,31 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                 acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
             }
             float* dst = dfeat + qpix * dfeat_ld + ch;
-            float4 o = ld4(dst);
-            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-            st4(dst, o);
+            if (overwrite) {                                  // the first writer of dfeat: every pixel of the tile is written
+                st4(dst, acc);
+            } else {
+                float4 o = ld4(dst);
+                o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+                st4(dst, o);
+            }
+        }
+    }
+    // ---- phase 3: a pixel with more sources than the list holds (a strongly contracting flow) adds the rest itself, behind
+    // phase 2's write of that pixel (still no atomics: q is ours)
+    if (__syncthreads_or(total1 > WG_MAXHIT)) {
+        if (total1 > WG_MAXHIT) {
+            float* dst = dfeat + ((long)(n * H + qy1) * W + qx1) * dfeat_ld;
+            scan(ly1, lx1, [&](int k, int sy, int sx, float wgt) {
+                if (k < WG_MAXHIT) return;
+                const size_t so = ((size_t)(n * H + qy1 + sy) * W + qx1 + sx) * dout_ld + dout_coff;
+                for (int ch = 0; ch < C; ch += 4) {           // C % 4 == 0
+                    const float4 v = ldx4(dout, so + ch, dout_bf16);
+                    // (atomics only for their L2 scope - phase 2 wrote this pixel from another wave; one thread per pixel, in
+                    // scan order: still deterministic)
+                    atomicAdd(dst + ch, wgt * v.x); atomicAdd(dst + ch + 1, wgt * v.y);
+                    atomicAdd(dst + ch + 2, wgt * v.z); atomicAdd(dst + ch + 3, wgt * v.w);
+                }
+            });
         }
     }
 }
@@ -549,28 +606,37 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
                       float* dflow, int dflow_ld, float* records, size_t records_bytes, int feat_bf16, int dout_bf16,
-                      void* stream) {
+                      int overwrite, void* stream) {
     NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
     NVQ_REQUIRE(!(feat_bf16 || dout_bf16) || records, "warp_backward: bf16-stored tensors need the gather form (records != NULL)");
     NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
     if (records) {                                            // gather form (deterministic, no atomics for |flow| < 4 px)
         const long npix = (long)N * H * W;
-        NVQ_REQUIRE(records_bytes >= (size_t)npix * 20 && aligned16(records), "warp_backward: records buffer needs 20 B per pixel");
+        NVQ_REQUIRE(records_bytes >= (size_t)npix * 20 + (overwrite ? 16 : 0) && aligned16(records),
+                    "warp_backward: records buffer needs 20 B per pixel (+ 16 B in the overwrite mode)");
         NVQ_REQUIRE(dout_ld % 4 == 0 && dout_coff % 4 == 0 && feat_ld % 4 == 0 && dfeat_ld % 4 == 0 && aligned16(dout) &&
                         aligned16(feat) && aligned16(dfeat),
                     "warp_backward: alignment");
         float4* rec_w = reinterpret_cast<float4*>(records);
         int* rec_code = reinterpret_cast<int*>(rec_w + npix);
         hipStream_t s = (hipStream_t)stream;
+        int* far_flag = overwrite ? rec_code + npix : nullptr;
+        if (far_flag && hipMemsetAsync(far_flag, 0, sizeof(int), s) != hipSuccess) return check_launch("warp_backward(flag)");
         hipLaunchKernelGGL(warp_bwd_src_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, feat,
-                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16, dout_bf16);
+                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16,
+                           dout_bf16, far_flag);
         int rc = check_launch("warp_backward(src)");
         if (rc) return rc;
         const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;
         hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout, dout_ld,
-                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, dout_bf16);
-        return check_launch("warp_backward(gather)");
+                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, dout_bf16, overwrite);
+        rc = check_launch("warp_backward(gather)");
+        if (rc || !overwrite) return rc;
+        hipLaunchKernelGGL(warp_bwd_far_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
+                           flow_ld, C, H, W, dfeat, dfeat_ld, npix, dout_bf16, far_flag);
+        return check_launch("warp_backward(far)");
     }
+    NVQ_REQUIRE(!overwrite, "warp_backward: the overwrite mode needs the gather form (records != NULL)");
     const long total = (long)N * H * W * (C < 64 ? C : 64);
     hipLaunchKernelGGL(warp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
                        dout_coff, feat, feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, total);

@@ -316,7 +316,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.shuffle_clamp_backward(dout, sv.passmask, g.s, du)
     _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", ws, 3, math=math)
     dfeat_all = _new(dev, NI, H, W, F)              # gradient w.r.t. the features of every frame (slot order)
-    dfeat_all[B:].zero_()                           # the centre frames' part is first written (out2 below), the rest added to
+    # the centre frames' part is first written by the upsampler's input-gradient conv (out2 below), the other frames' by the
+    # warp backward (overwrite mode); everything later is added to
     dfeat_c = dfeat_all[:B]
     dg = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
@@ -413,7 +414,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             t = g.slots[j]
             lo, hi = (j - 1) * B, j * B
             K.warp_backward(Sl(daligned, F, t * F), Sl(sv.feat_oth).images(lo, hi), sv.flow[lo:hi],
-                            Sl(dfeat_oth).images(lo, hi), dflow[lo:hi])
+                            Sl(dfeat_oth).images(lo, hi), dflow[lo:hi], overwrite=True)
         acts = sv.flow_acts          # [corr(96), f1(128), f2(64), f3(32), flow(4)]
         chans = [81, 128, 64, 32, 2]
         dy_t, dy_c = dflow, 2

@@ -97,7 +97,7 @@ SIGNATURES = {
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, vp]),
+    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
     "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
     "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, vp]),
@@ -706,14 +706,16 @@ def warp_forward(feat: Sl, flow: torch.Tensor, out: Sl):
                                  out.ld, out.coff, feat.bf16, out.bf16, stream()), "nvq_warp_forward")
 
 
-def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torch.Tensor, gather: bool = True):
-    """gather=True: atomics-free two-pass form (needs 20 B of scratch per pixel, allocated here); False: scatter form."""
+def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torch.Tensor, gather: bool = True,
+                  overwrite: bool = False):
+    """gather=True: atomics-free two-pass form (needs 20 B of scratch per pixel, allocated here); False: scatter form.
+    overwrite: dfeat is written instead of added to (gather form): no zero fill before, no read-modify-write here."""
     N, H, W, _ = feat.t.shape
-    rec = torch.empty(N * H * W * 5, dtype=torch.float32, device=flow.device) if gather else None
+    rec = torch.empty(N * H * W * 5 + 4, dtype=torch.float32, device=flow.device) if gather else None
     check(lib().nvq_warp_backward(ptr(dout.t), dout.ld, dout.coff, feat.base(), feat.ld, ptr(flow),
                                   flow.shape[-1], feat.c, N, H, W, dfeat.base(), dfeat.ld, ptr(dflow),
                                   dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, feat.bf16, dout.bf16,
-                                  stream()),
+                                  int(overwrite), stream()),
           "nvq_warp_backward")
 
 

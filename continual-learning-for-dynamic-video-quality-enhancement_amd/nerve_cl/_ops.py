@@ -840,8 +840,8 @@ class Warp(torch.autograd.Function):
     def backward(ctx, dout):
         feat, flow = ctx.saved_tensors
         dout = dout.contiguous()
-        dfeat, dflow = torch.zeros_like(feat), torch.zeros_like(flow)
-        K.warp_backward(Sl(dout, ctx.C), Sl(feat, ctx.C), flow, Sl(dfeat, ctx.C), dflow)
+        dfeat, dflow = torch.empty_like(feat), torch.empty_like(flow)
+        K.warp_backward(Sl(dout, ctx.C), Sl(feat, ctx.C), flow, Sl(dfeat, ctx.C), dflow, overwrite=True)
         return dfeat, dflow, None
 
 

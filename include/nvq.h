@@ -299,8 +299,9 @@ int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
 int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow_ld,
                      int C, int N, int H, int W, float* out, int out_ld, int out_coff,
                      int feat_bf16, int out_bf16, void* stream);
-/* dfeat must be pre-initialised (the gradient is ADDED to it); dflow [N,H,W,dflow_ld] gets channels 0,1 written and
- * 2..dflow_ld-1 zeroed.  records == NULL: scatter form, 4 float atomics per (pixel, channel).  records != NULL (20 bytes
+/* overwrite == 0: dfeat must be pre-initialised (the gradient is ADDED to it); overwrite != 0 (gather form only, 16 more
+ * bytes of records): dfeat [N,H,W,0..C) is WRITTEN - no zero fill before and no read-modify-write in the call.  dflow
+ * [N,H,W,dflow_ld] gets channels 0,1 written and 2..dflow_ld-1 zeroed.  records == NULL: scatter form, 4 float atomics per (pixel, channel).  records != NULL (20 bytes
  * per pixel of scratch, 16-byte aligned): gather form - a per-source pass writes the flow gradient and a {corner offset,
  * 4 weights} record, a per-destination pass collects the contributions from the 9x9 window around each pixel; no atomics
  * and a fixed summation order for every source whose flow is shorter than 4 pixels (longer ones are still scattered).
@@ -309,7 +310,7 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat,
                       int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
                       float* dfeat, int dfeat_ld, float* dflow, int dflow_ld,
-                      float* records, size_t records_bytes, int feat_bf16, int dout_bf16, void* stream);
+                      float* records, size_t records_bytes, int feat_bf16, int dout_bf16, int overwrite, void* stream);
 
 /* ------------------------------------------------------------------ temporal aggregation
  * TemporalAggregator.forward softmax + weighted sum, super_resolution.py:174,203-204:

@@ -343,6 +343,37 @@ def test_warp_forward_backward(K, C, N, H, W, mag, gather):
     assert rel(from_nhwc(dfeat) - base, feat.grad) < 5e-5
     assert rel(from_nhwc(dflow, 2), flow.grad) < 2e-4
     assert dflow[..., 2:].abs().max().item() == 0
+    if gather:
+        # overwrite mode: dfeat is written (whatever it held), far sources scattered behind the gather pass
+        dfeat2 = torch.full((N, H, W, C), float("nan"), device="cuda")
+        dflow2 = torch.empty(N, H, W, 4, device="cuda")
+        K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat2), dflow2, overwrite=True)
+        assert rel(from_nhwc(dfeat2), feat.grad) < 5e-5 and torch.equal(dflow2, dflow)
+    else:
+        with pytest.raises(RuntimeError, match="overwrite mode needs the gather form"):
+            K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat), dflow, gather=False, overwrite=True)
+
+
+@pytest.mark.parametrize("overwrite", [False, True])
+def test_warp_backward_contracting_flow_overflows_the_hit_list(K, overwrite):
+    """A flow that sends a 7 x 7 neighbourhood to (nearly) one point gives destination pixels more contributing sources than the
+    gather pass lists (12): the rest is added by the pixel's own thread behind the listed ones, in both modes."""
+    C, N, H, W = 64, 1, 16, 40
+    feat = rnd(N, C, H, W).requires_grad_()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    cy, cx = 8.3, 20.6
+    near = ((ys - cy).abs() <= 3.5) & ((xs - cx).abs() <= 3.5)
+    fl = torch.stack([torch.where(near, 0.97 * (cx - xs), torch.zeros(())), torch.where(near, 0.97 * (cy - ys), torch.zeros(()))])
+    flow = (fl[None] + 0.05 * rnd(N, 2, H, W, seed=2)).requires_grad_()
+    sr_oracle.warp(feat, flow).backward(rnd(N, C, H, W, seed=4))
+    dal = to_nhwc(rnd(N, C, H, W, seed=4))
+    base = rnd(N, C, H, W, seed=8)
+    dfeat = to_nhwc(base)
+    dflow = torch.empty(N, H, W, 4, device="cuda")
+    K.warp_backward(K.Sl(dal), K.Sl(to_nhwc(feat.detach())), to_nhwc(flow.detach(), 4), K.Sl(dfeat), dflow, overwrite=overwrite)
+    got = from_nhwc(dfeat) - (0 if overwrite else base)
+    assert rel(got, feat.grad) < 5e-5
+    assert rel(from_nhwc(dflow, 2), flow.grad) < 2e-4
 
 
 # ----------------------------------------------------------------------------- aggregation
