@@ -29,47 +29,65 @@ static inline int tsum_blocks_host(int H, int W) {
 
 // ---------------------------------------------------------------- softmax-weighted sum
 // grid (nblk, N)
+template <int TMAX, int TU, bool AB>
 __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__ aligned, int aligned_ld,
                                                        const float* __restrict__ logits, int logits_ld, int T,
                                                        int C, long HW, float* __restrict__ attn, int attn_ld,
                                                        float* __restrict__ weighted, int weighted_ld,
-                                                       float* __restrict__ gap_partial, int aligned_bf16) {
+                                                       float* __restrict__ gap_partial) {
+    constexpr int aligned_bf16 = AB;              // (a template parameter: as a run-time flag every ldx4 is a branch with its own wait)
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
     const int npl = 256 / C4;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     const long base = (long)blockIdx.y * HW;
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long p = (long)blockIdx.x * npl + pl; p < HW; p += (long)gridDim.x * npl) {
-        const long pix = base + p;
-        float lg[NVQ_MAX_T];
-        float mx = -3.4e38f;
+    // TU pixels per trip, all their loads issued before the first use (one pixel per trip left 36 B per lane in flight and the
+    // kernel at 2.5 TB/s); a pixel past the end is clamped for its loads and skipped at the stores.  T <= TMAX (4: TU = 4;
+    // 8: TU = 2 - the register budget of four waves per SIMD)
+    const long stride = (long)gridDim.x * npl;
+    for (long p0 = (long)blockIdx.x * npl + pl; p0 < HW; p0 += TU * stride) {
+        float lg[TU][TMAX];
+        float4 v[TU][TMAX];
 #pragma unroll
-        for (int t = 0; t < NVQ_MAX_T; ++t) {
-            lg[t] = t < T ? logits[pix * logits_ld + t] : -3.4e38f;
-            mx = fmaxf(mx, lg[t]);
-        }
-        float den = 0.f;
+        for (int u = 0; u < TU; ++u) {
+            const long pu = p0 + u * stride;
+            const long pix = base + (pu < HW ? pu : p0);
 #pragma unroll
-        for (int t = 0; t < NVQ_MAX_T; ++t) {
-            lg[t] = t < T ? __expf(lg[t] - mx) : 0.f;
-            den += lg[t];
-        }
-        const float inv = 1.f / den;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < NVQ_MAX_T; ++t) {
-            if (t < T) {
-                const float a = lg[t] * inv;
-                const float4 v = ldx4(aligned, (size_t)pix * aligned_ld + t * C + 4 * c4, aligned_bf16);
-                o.x += v.x * a; o.y += v.y * a; o.z += v.z * a; o.w += v.w * a;
-                if (c4 == 0) attn[pix * attn_ld + t] = a;
+            for (int t = 0; t < TMAX; ++t) {
+                lg[u][t] = t < T ? logits[pix * logits_ld + t] : -3.4e38f;
+                if (t < T) v[u][t] = ldx4(aligned, (size_t)pix * aligned_ld + t * C + 4 * c4, aligned_bf16);
             }
         }
-        if (c4 == 0)
-            for (int t = T; t < attn_ld; ++t) attn[pix * attn_ld + t] = 0.f;
-        st4(weighted + pix * weighted_ld + 4 * c4, o);
-        gsum.x += o.x; gsum.y += o.y; gsum.z += o.z; gsum.w += o.w;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const long pu = p0 + u * stride;
+            if (pu >= HW) break;
+            const long pix = base + pu;
+            float mx = -3.4e38f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) mx = fmaxf(mx, lg[u][t]);
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                lg[u][t] = t < T ? __expf(lg[u][t] - mx) : 0.f;
+                den += lg[u][t];
+            }
+            const float inv = 1.f / den;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                if (t < T) {
+                    const float a = lg[u][t] * inv;
+                    o.x += v[u][t].x * a; o.y += v[u][t].y * a; o.z += v[u][t].z * a; o.w += v[u][t].w * a;
+                    if (c4 == 0) attn[pix * attn_ld + t] = a;
+                }
+            }
+            if (c4 == 0)
+                for (int t = T; t < attn_ld; ++t) attn[pix * attn_ld + t] = 0.f;
+            st4(weighted + pix * weighted_ld + 4 * c4, o);
+            gsum.x += o.x; gsum.y += o.y; gsum.z += o.z; gsum.w += o.w;
+        }
     }
     const float4 r = plane_reduce4b(gsum, buf, C4, npl);
     if ((int)threadIdx.x < C4)
@@ -436,8 +454,11 @@ int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, 
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && logits_ld >= T && attn_ld >= T, "tsum_forward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && weighted_ld % 4 == 0 && aligned_ld >= T * C, "tsum_forward: ld");
     const dim3 grid(tsum_blocks_host(H, W), N);
-    hipLaunchKernelGGL(tsum_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, aligned, aligned_ld, logits, logits_ld,
-                       T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, gap_partial, aligned_bf16);
+#define NVQ_TS(M_, U_, A_) hipLaunchKernelGGL((tsum_fwd_kernel<M_, U_, A_>), grid, dim3(256), 0, (hipStream_t)stream, aligned, aligned_ld, \
+                                              logits, logits_ld, T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, gap_partial)
+    if (T <= 4) { if (aligned_bf16) NVQ_TS(4, 4, true); else NVQ_TS(4, 4, false); }
+    else { if (aligned_bf16) NVQ_TS(NVQ_MAX_T, 2, true); else NVQ_TS(NVQ_MAX_T, 2, false); }
+#undef NVQ_TS
     return check_launch("tsum_forward");
 }
 

@@ -240,30 +240,68 @@ __device__ __forceinline__ WarpGeom warp_geom(float fx, float fy, int x, int y, 
     return g;
 }
 
+// A workgroup takes 256 consecutive pixels.  Phase A: one THREAD per pixel does the geometry (two fp32 divisions, floors,
+// validity) once and leaves {4 corner pixel indices, 4 weights} in LDS; phase B: 16 lanes per pixel (8 bytes of channels each)
+// read them back as two broadcast b128 reads and do the loads.  With the geometry in every one of a pixel's 16 lanes the
+// kernel was VALU-bound (~200 instructions per lane, 0.53 ms for 8 x 540 x 960 x 64 = 2.0 TB/s; more pixels per thread made it
+// slower, not faster).  Corner loads are unconditional (a corner outside the image reads the image's first pixel with weight 0:
+// fma(v, 0, acc) == acc, so the sum and its order are those of the reference).
+// The storage types are template parameters: as run-time flags every ldx4 was a branch with its own vmcnt(0) behind the load -
+// the four corner loads of a pixel ran one after the other (2.0 -> 3.6 TB/s with the geometry hoisted as well).
+constexpr int WT_H = 8, WT_W = 32, WP = WT_H * WT_W;
+template <bool FB, bool OB>
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ feat, int feat_ld,
                                                        const float* __restrict__ flow, int flow_ld, int C,
                                                        int H, int W, float* __restrict__ out, int out_ld,
-                                                       int out_coff, long total, int feat_bf16, int out_bf16) {
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    if (gid >= total) return;
-    const int C4 = C >> 2;
-    const long pix = idiv(gid, C4, total);
-    const int c4 = (int)(gid - pix * C4);
-    const long rowi = idiv(pix, W, total);
-    const int x = (int)(pix - rowi * W);
-    const int y = (int)(rowi - idiv(rowi, H, total) * H);
-    const long img = pix - ((long)y * W + x);  // first pixel of this image
-    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.vnw) { const float4 v = ldx4(feat, (size_t)(img + (long)g.y0 * W + g.x0) * feat_ld + 4 * c4, feat_bf16);
-        acc.x += v.x * g.wnw; acc.y += v.y * g.wnw; acc.z += v.z * g.wnw; acc.w += v.w * g.wnw; }
-    if (g.vne) { const float4 v = ldx4(feat, (size_t)(img + (long)g.y0 * W + g.x0 + 1) * feat_ld + 4 * c4, feat_bf16);
-        acc.x += v.x * g.wne; acc.y += v.y * g.wne; acc.z += v.z * g.wne; acc.w += v.w * g.wne; }
-    if (g.vsw) { const float4 v = ldx4(feat, (size_t)(img + (long)(g.y0 + 1) * W + g.x0) * feat_ld + 4 * c4, feat_bf16);
-        acc.x += v.x * g.wsw; acc.y += v.y * g.wsw; acc.z += v.z * g.wsw; acc.w += v.w * g.wsw; }
-    if (g.vse) { const float4 v = ldx4(feat, (size_t)(img + (long)(g.y0 + 1) * W + g.x0 + 1) * feat_ld + 4 * c4, feat_bf16);
-        acc.x += v.x * g.wse; acc.y += v.y * g.wse; acc.z += v.z * g.wse; acc.w += v.w * g.wse; }
-    stx4(out, (size_t)pix * out_ld + out_coff + 4 * c4, out_bf16, acc);
+                                                       int out_coff, int tilesX, int tilesY) {
+    constexpr int feat_bf16 = FB, out_bf16 = OB;
+    __shared__ int4 so[WP];
+    __shared__ float4 sw[WP];
+    // 8 x 32-pixel tiles in XCD order: the two feature rows a pixel row reads are shared with the rows above and below inside
+    // the tile (L1) and with the neighbouring tiles of the same XCD (L2) - as 256 consecutive pixels of one row every
+    // feature row came in twice
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int img = n * H * W;                                // first pixel of this image (N*H*W < 2^31: host check)
+    {
+        const int x = tx * WT_W + (threadIdx.x & (WT_W - 1)), y = ty * WT_H + (threadIdx.x >> 5);
+        int4 o = make_int4(0, 0, 0, 0);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < W && y < H) {
+            const long pix = img + (long)y * W + x;
+            const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+            o = make_int4(img + (g.vnw ? g.y0 * W + g.x0 : 0), img + (g.vne ? g.y0 * W + g.x0 + 1 : 0),
+                          img + (g.vsw ? (g.y0 + 1) * W + g.x0 : 0), img + (g.vse ? (g.y0 + 1) * W + g.x0 + 1 : 0));
+            w = make_float4(g.vnw ? g.wnw : 0.f, g.vne ? g.wne : 0.f, g.vsw ? g.wsw : 0.f, g.vse ? g.wse : 0.f);
+        }
+        so[threadIdx.x] = o;
+        sw[threadIdx.x] = w;
+    }
+    __syncthreads();
+    const int c4 = threadIdx.x & 15;
+#pragma unroll 4
+    for (int it = 0; it < WP / 16; ++it) {
+        const int pl = it * 16 + (threadIdx.x >> 4);
+        const int x = tx * WT_W + (pl & (WT_W - 1)), y = ty * WT_H + (pl >> 5);
+        if (x >= W || y >= H) continue;
+        const long pix = img + (long)y * W + x;
+        const int4 o = so[pl];
+        const float4 w = sw[pl];
+        for (int ch = 4 * c4; ch < C; ch += 64) {
+            const float4 v0 = ldx4(feat, (size_t)o.x * feat_ld + ch, feat_bf16);
+            const float4 v1 = ldx4(feat, (size_t)o.y * feat_ld + ch, feat_bf16);
+            const float4 v2 = ldx4(feat, (size_t)o.z * feat_ld + ch, feat_bf16);
+            const float4 v3 = ldx4(feat, (size_t)o.w * feat_ld + ch, feat_bf16);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x += v0.x * w.x; acc.y += v0.y * w.x; acc.z += v0.z * w.x; acc.w += v0.w * w.x;
+            acc.x += v1.x * w.y; acc.y += v1.y * w.y; acc.z += v1.z * w.y; acc.w += v1.w * w.y;
+            acc.x += v2.x * w.z; acc.y += v2.y * w.z; acc.z += v2.z * w.z; acc.w += v2.w * w.z;
+            acc.x += v3.x * w.w; acc.y += v3.y * w.w; acc.z += v3.z * w.w; acc.w += v3.w * w.w;
+            stx4(out, (size_t)pix * out_ld + out_coff + ch, out_bf16, acc);
+        }
+    }
 }
 
 // One thread per (pixel, channel): the lanes of a pixel issue their float atomics on C consecutive floats
@@ -333,63 +371,99 @@ constexpr int WG_TH = 8, WG_TW = 32;            // destination tile
 constexpr int WG_HH = WG_TH + 2 * WG_R, WG_HW = WG_TW + 2 * WG_R;   // 16 x 40 records
 
 // 16 lanes per pixel x float4 = 64 channels per pass (C % 4 == 0; lanes with c4*4 >= C idle; C > 64: channel loop)
+template <bool FB, bool DB>
 __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                            const float* __restrict__ feat, int feat_ld,
                                                            const float* __restrict__ flow, int flow_ld, int C, int H, int W,
                                                            float* __restrict__ dfeat, int dfeat_ld,
                                                            float* __restrict__ dflow, int dflow_ld,
-                                                           float4* __restrict__ rec_w, int* __restrict__ rec_code, long npix,
-                                                           int feat_bf16, int dout_bf16, int* __restrict__ far_flag) {
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    const long pix = gid >> 4;
-    if (pix >= npix) return;                                  // (whole 16-lane groups leave together)
-    const int c4 = gid & 15;
-    const long rowi = idiv(pix, W, npix);
-    const int x = (int)(pix - rowi * W);
-    const int y = (int)(rowi - idiv(rowi, H, npix) * H);
-    const long img = pix - ((long)y * W + x);
-    const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
-    const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
-    const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
-    const int ox = g.x0 - x, oy = g.y0 - y;
-    const bool any = g.vnw || g.vne || g.vsw || g.vse;
-    const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
-    // far_flag != NULL (overwrite mode: dfeat is not initialised yet): a far source is only flagged here and scattered by
-    // warp_bwd_far_kernel behind the gather pass
-    const bool scatter = any && !near && far_flag == nullptr;
-    if (any && !near && far_flag != nullptr && c4 == 0) *far_flag = 1;
-    float gix = 0.f, giy = 0.f;
-    for (int ch = 4 * c4; ch < C; ch += 64) {
-        const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
-        auto corner = [&](bool valid, long o, float wgt, float sx, float sy) {
-            if (!valid) return;
-            const float4 f = ldx4(feat, (size_t)o * feat_ld + ch, feat_bf16);
-            const float dsum = f.x * go.x + f.y * go.y + f.z * go.z + f.w * go.w;
-            gix += sx * dsum;
-            giy += sy * dsum;
-            if (scatter) {
-                float* db = dfeat + o * dfeat_ld + ch;
-                atomicAdd(db, go.x * wgt); atomicAdd(db + 1, go.y * wgt); atomicAdd(db + 2, go.z * wgt); atomicAdd(db + 3, go.w * wgt);
-            }
-        };
-        corner(g.vnw, img + (long)g.y0 * W + g.x0, g.wnw, -(y_se - g.iy), -(x_se - g.ix));
-        corner(g.vne, img + (long)g.y0 * W + g.x0 + 1, g.wne, (y_se - g.iy), -(g.ix - fx0));
-        corner(g.vsw, img + (long)(g.y0 + 1) * W + g.x0, g.wsw, -(g.iy - fy0), (x_se - g.ix));
-        corner(g.vse, img + (long)(g.y0 + 1) * W + g.x0 + 1, g.wse, (g.iy - fy0), (g.ix - fx0));
+                                                           float4* __restrict__ rec_w, int* __restrict__ rec_code, int tilesX,
+                                                           int tilesY, int* __restrict__ far_flag) {
+    constexpr int feat_bf16 = FB, dout_bf16 = DB;
+    // Phase A: one thread per pixel - geometry, record, and what phase B needs (corner indices, corner weights for a scatter, the
+    // four (d ix, d iy) factors of the flow gradient) into LDS.  Phase B: 16 lanes per pixel do the loads and the channel sums.
+    // (With the geometry in every one of the 16 lanes the kernel was VALU-bound, see warp_fwd_kernel.)
+    __shared__ int4 so[WP];
+    __shared__ float4 swt[WP], ssx[WP], ssy[WP];
+    __shared__ int sflag[WP];                                  // bit k: corner k valid; bit 4: scatter this source
+    int bt = xcd_tile(blockIdx.x, gridDim.x);                 // 8 x 32-pixel tiles in XCD order, see warp_fwd_kernel
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int img = n * H * W;                                // (N*H*W < 2^31: host check)
+    {
+        const int x = tx * WT_W + (threadIdx.x & (WT_W - 1)), y = ty * WT_H + (threadIdx.x >> 5);
+        int4 o = make_int4(0, 0, 0, 0);
+        float4 wt = make_float4(0.f, 0.f, 0.f, 0.f), sx = wt, sy = wt;
+        int flag = 0;
+        if (x < W && y < H) {
+            const long pix = img + (long)y * W + x;
+            const WarpGeom g = warp_geom(flow[pix * flow_ld], flow[pix * flow_ld + 1], x, y, H, W);
+            const float fx0 = floorf(g.ix), fy0 = floorf(g.iy);
+            const float x_se = fx0 + 1.f, y_se = fy0 + 1.f;
+            const int ox = g.x0 - x, oy = g.y0 - y;
+            const bool any = g.vnw || g.vne || g.vsw || g.vse;
+            const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
+            // far_flag != NULL (overwrite mode: dfeat is not initialised yet): a far source is only flagged here and scattered by
+            // warp_bwd_far_kernel behind the gather pass
+            const bool scatter = any && !near && far_flag == nullptr;
+            if (any && !near && far_flag != nullptr) *far_flag = 1;
+            o = make_int4(img + (g.vnw ? g.y0 * W + g.x0 : 0), img + (g.vne ? g.y0 * W + g.x0 + 1 : 0),
+                          img + (g.vsw ? (g.y0 + 1) * W + g.x0 : 0), img + (g.vse ? (g.y0 + 1) * W + g.x0 + 1 : 0));
+            wt = make_float4(g.wnw, g.wne, g.wsw, g.wse);
+            sx = make_float4(-(y_se - g.iy), (y_se - g.iy), -(g.iy - fy0), (g.iy - fy0));
+            sy = make_float4(-(x_se - g.ix), -(g.ix - fx0), (x_se - g.ix), (g.ix - fx0));
+            flag = (g.vnw ? 1 : 0) | (g.vne ? 2 : 0) | (g.vsw ? 4 : 0) | (g.vse ? 8 : 0) | (scatter ? 16 : 0);
+            const bool rec = any && near;
+            rec_w[pix] = rec ? make_float4(g.vnw ? g.wnw : 0.f, g.vne ? g.wne : 0.f, g.vsw ? g.wsw : 0.f, g.vse ? g.wse : 0.f)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            rec_code[pix] = rec ? ((oy + WG_R) << 4) | (ox + WG_R) : -1;
+        }
+        so[threadIdx.x] = o; swt[threadIdx.x] = wt; ssx[threadIdx.x] = sx; ssy[threadIdx.x] = sy; sflag[threadIdx.x] = flag;
     }
-    gix = group_sum(gix, 16);
-    giy = group_sum(giy, 16);
-    if (c4 == 0) {
-        const float gx = 2.0f * ((gix * ((float)(W - 1) / 2.f)) / (float)(W - 1));
-        const float gyv = 2.0f * ((giy * ((float)(H - 1) / 2.f)) / (float)(H - 1));
-        float* dp = dflow + pix * dflow_ld;
-        dp[0] = gx;
-        dp[1] = gyv;
-        for (int k = 2; k < dflow_ld; ++k) dp[k] = 0.f;
-        const bool rec = any && near;
-        rec_w[pix] = rec ? make_float4(g.vnw ? g.wnw : 0.f, g.vne ? g.wne : 0.f, g.vsw ? g.wsw : 0.f, g.vse ? g.wse : 0.f)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-        rec_code[pix] = rec ? ((oy + WG_R) << 4) | (ox + WG_R) : -1;
+    __syncthreads();
+    const int c4 = threadIdx.x & 15;
+#pragma unroll 2
+    for (int it = 0; it < WP / 16; ++it) {
+        const int pl = it * 16 + (threadIdx.x >> 4);
+        const int x = tx * WT_W + (pl & (WT_W - 1)), y = ty * WT_H + (pl >> 5);
+        if (x >= W || y >= H) continue;                       // (whole 16-lane groups skip together)
+        const long pix = img + (long)y * W + x;
+        const int4 o = so[pl];
+        const float4 wt = swt[pl], sx = ssx[pl], sy = ssy[pl];
+        const int flag = sflag[pl];
+        float gix = 0.f, giy = 0.f;
+        for (int ch = 4 * c4; ch < C; ch += 64) {
+            const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
+            // unconditional corner loads (an outside corner reads the image's first pixel and contributes nothing)
+            const float4 f0 = ldx4(feat, (size_t)o.x * feat_ld + ch, feat_bf16), f1 = ldx4(feat, (size_t)o.y * feat_ld + ch, feat_bf16);
+            const float4 f2 = ldx4(feat, (size_t)o.z * feat_ld + ch, feat_bf16), f3 = ldx4(feat, (size_t)o.w * feat_ld + ch, feat_bf16);
+            auto corner = [&](int bit, int oo, const float4& f, float wgt, float csx, float csy) {
+                if (!(flag & bit)) return;
+                const float dsum = f.x * go.x + f.y * go.y + f.z * go.z + f.w * go.w;
+                gix += csx * dsum;
+                giy += csy * dsum;
+                if (flag & 16) {
+                    float* db = dfeat + (size_t)oo * dfeat_ld + ch;
+                    atomicAdd(db, go.x * wgt); atomicAdd(db + 1, go.y * wgt); atomicAdd(db + 2, go.z * wgt); atomicAdd(db + 3, go.w * wgt);
+                }
+            };
+            corner(1, o.x, f0, wt.x, sx.x, sy.x);
+            corner(2, o.y, f1, wt.y, sx.y, sy.y);
+            corner(4, o.z, f2, wt.z, sx.z, sy.z);
+            corner(8, o.w, f3, wt.w, sx.w, sy.w);
+        }
+        gix = group_sum(gix, 16);
+        giy = group_sum(giy, 16);
+        if (c4 == 0) {
+            // grid_sample multiplies by (size-1)/2; the normalisation's autograd divides by (size-1) and doubles
+            const float gx = 2.0f * ((gix * ((float)(W - 1) / 2.f)) / (float)(W - 1));
+            const float gyv = 2.0f * ((giy * ((float)(H - 1) / 2.f)) / (float)(H - 1));
+            float* dp = dflow + pix * dflow_ld;
+            dp[0] = gx;
+            dp[1] = gyv;
+            for (int k = 2; k < dflow_ld; ++k) dp[k] = 0.f;
+        }
     }
 }
 
@@ -400,10 +474,8 @@ __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restri
                                                            float* __restrict__ dfeat, int dfeat_ld, long npix, int dout_bf16,
                                                            const int* __restrict__ far_flag) {
     if (*far_flag == 0) return;
-    const long gid = blockIdx.x * 256L + threadIdx.x;
-    const long pix = gid >> 4;
+    const long pix = blockIdx.x * 256L + threadIdx.x;        // one thread per source pixel (far sources are rare)
     if (pix >= npix) return;
-    const int c4 = gid & 15;
     const long rowi = idiv(pix, W, npix);
     const int x = (int)(pix - rowi * W);
     const int y = (int)(rowi - idiv(rowi, H, npix) * H);
@@ -413,7 +485,7 @@ __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restri
     const bool any = g.vnw || g.vne || g.vsw || g.vse;
     const bool near = ox >= -WG_R && ox <= WG_R - 1 && oy >= -WG_R && oy <= WG_R - 1;
     if (!any || near) return;
-    for (int ch = 4 * c4; ch < C; ch += 64) {
+    for (int ch = 0; ch < C; ch += 4) {
         const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
         auto corner = [&](bool valid, long o, float wgt) {
             if (!valid) return;
@@ -432,11 +504,13 @@ __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restri
 // each, so a pixel's 64 channels are one coalesced 256-byte access) walk the lists and add into dfeat.
 constexpr int WG_MAXHIT = 12;                   // list length per pixel; further hits (a strongly contracting flow) are
                                                 // applied by phase 1 itself, one pixel per lane
+template <bool DB>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                               const float4* __restrict__ rec_w,
                                                               const int* __restrict__ rec_code, int C, int H, int W,
                                                               int tilesX, int tilesY, float* __restrict__ dfeat,
-                                                              int dfeat_ld, int dout_bf16, int overwrite) {
+                                                              int dfeat_ld, int overwrite) {
+    constexpr int dout_bf16 = DB;
     __shared__ float4 lw[WG_HH * WG_HW];
     __shared__ int lc[WG_HH * WG_HW];
     __shared__ int hit_n[WG_TH * WG_TW];
@@ -495,12 +569,23 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
         const long qpix = (long)(n * H + qy) * W + qx;
         for (int ch = 4 * c4; ch < C; ch += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < cnt; ++k) {
-                const int hp = hit_p[qi * WG_MAXHIT + k];
-                const float wgt = hit_w[qi * WG_MAXHIT + k];
-                const int sy = (hp >> 4) - WG_R, sx = (hp & 15) - WG_R;
-                const float4 v = ldx4(dout, ((size_t)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff + ch, dout_bf16);
-                acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+            // four hits per trip, their loads in flight together (one load -> wait -> fma per hit serialised a memory latency per
+            // hit); a slot past the list repeats hit 0 with weight 0: fma(0, v, acc) == acc, so the sum and its order are unchanged
+            for (int k0 = 0; k0 < cnt; k0 += 4) {
+                float4 v[4];
+                float wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = k0 + u < cnt;
+                    const int hp = hit_p[qi * WG_MAXHIT + (in ? k0 + u : 0)];
+                    wv[u] = in ? hit_w[qi * WG_MAXHIT + k0 + u] : 0.f;
+                    const int sy = (hp >> 4) - WG_R, sx = (hp & 15) - WG_R;
+                    v[u] = ldx4(dout, ((size_t)(n * H + qy + sy) * W + qx + sx) * dout_ld + dout_coff + ch, dout_bf16);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += wv[u] * v[u].x; acc.y += wv[u] * v[u].y; acc.z += wv[u] * v[u].z; acc.w += wv[u] * v[u].w;
+                }
             }
             float* dst = dfeat + qpix * dfeat_ld + ch;
             if (overwrite) {                                  // the first writer of dfeat: every pixel of the tile is written
@@ -597,9 +682,14 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
     NVQ_REQUIRE(C % 4 == 0 && feat_ld % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0 && flow_ld >= 2 &&
                     aligned16(feat) && aligned16(out),
                 "warp_forward: alignment");
-    const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, feat_ld,
-                       flow, flow_ld, C, H, W, out, out_ld, out_coff, total, feat_bf16, out_bf16);
+    const long npix = (long)N * H * W;
+    NVQ_REQUIRE(npix < ((long)1 << 31), "warp_forward: too many pixels");
+    const int tilesX = (W + WT_W - 1) / WT_W, tilesY = (H + WT_H - 1) / WT_H;
+#define NVQ_WF(F_, O_) hipLaunchKernelGGL((warp_fwd_kernel<F_, O_>), dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, \
+                                          (hipStream_t)stream, feat, feat_ld, flow, flow_ld, C, H, W, out, out_ld, out_coff, tilesX, tilesY)
+    if (feat_bf16) { if (out_bf16) NVQ_WF(true, true); else NVQ_WF(true, false); }
+    else { if (out_bf16) NVQ_WF(false, true); else NVQ_WF(false, false); }
+#undef NVQ_WF
     return check_launch("warp_forward");
 }
 
@@ -622,17 +712,26 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
         hipStream_t s = (hipStream_t)stream;
         int* far_flag = overwrite ? rec_code + npix : nullptr;
         if (far_flag && hipMemsetAsync(far_flag, 0, sizeof(int), s) != hipSuccess) return check_launch("warp_backward(flag)");
-        hipLaunchKernelGGL(warp_bwd_src_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, feat,
-                           feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow, dflow_ld, rec_w, rec_code, npix, feat_bf16,
-                           dout_bf16, far_flag);
+        NVQ_REQUIRE(npix < ((long)1 << 31), "warp_backward: too many pixels");
+        const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;
+        static_assert(WG_TW == WT_W && WG_TH == WT_H, "the src and gather passes share the tile shape");
+#define NVQ_WS(F_, D_) hipLaunchKernelGGL((warp_bwd_src_kernel<F_, D_>), dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, \
+                                          dout, dout_ld, dout_coff, feat, feat_ld, flow, flow_ld, C, H, W, dfeat, dfeat_ld, dflow,       \
+                                          dflow_ld, rec_w, rec_code, tilesX, tilesY, far_flag)
+        if (feat_bf16) { if (dout_bf16) NVQ_WS(true, true); else NVQ_WS(true, false); }
+        else { if (dout_bf16) NVQ_WS(false, true); else NVQ_WS(false, false); }
+#undef NVQ_WS
         int rc = check_launch("warp_backward(src)");
         if (rc) return rc;
-        const int tilesX = (W + WG_TW - 1) / WG_TW, tilesY = (H + WG_TH - 1) / WG_TH;
-        hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout, dout_ld,
-                           dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, dout_bf16, overwrite);
+        if (dout_bf16)
+            hipLaunchKernelGGL(warp_bwd_gather_kernel<true>, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout,
+                               dout_ld, dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, overwrite);
+        else
+            hipLaunchKernelGGL(warp_bwd_gather_kernel<false>, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout,
+                               dout_ld, dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, overwrite);
         rc = check_launch("warp_backward(gather)");
         if (rc || !overwrite) return rc;
-        hipLaunchKernelGGL(warp_bwd_far_kernel, dim3(ceil_div(npix * 16, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
+        hipLaunchKernelGGL(warp_bwd_far_kernel, dim3(ceil_div(npix, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
                            flow_ld, C, H, W, dfeat, dfeat_ld, npix, dout_bf16, far_flag);
         return check_launch("warp_backward(far)");
     }

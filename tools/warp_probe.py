@@ -1,0 +1,34 @@
+"""Time the warp kernels alone at the cfg2 shape: 8 images of 540 x 960, 64 channels, bf16 features, flows of ~1 px.
+usage: python tools/warp_probe.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                "continual-learning-for-dynamic-video-quality-enhancement_amd"))
+from nerve_cl import _nvq as K  # noqa: E402
+from dwpw_probe import timed  # noqa: E402
+
+N, H, W, C = 8, 540, 960, 64
+dev = "cuda"
+feat = torch.randn(N, H, W, C, device=dev).bfloat16()
+flow = torch.randn(N, H, W, 4, device=dev) * 1.2
+out = torch.empty(N, H, W, 3 * C, device=dev, dtype=torch.bfloat16)
+dout = torch.randn(N, H, W, 3 * C, device=dev).bfloat16()
+dfeat = torch.empty(N, H, W, C, device=dev)
+dflow = torch.empty(N, H, W, 4, device=dev)
+unit = N * H * W * C * 2 / 1e9
+for mag in (0.05, 1.2):
+    flow = torch.randn(N, H, W, 4, device=dev) * mag
+    ms = timed(lambda: K.warp_forward(K.Sl(feat), flow, K.Sl(out, C, 2 * C)), 20)
+    print(f"warp_forward |flow| ~ {mag}: {ms:.3f} ms ({2 * unit / ms:.2f} TB/s over feat + out)")
+    dense = torch.empty(N, H, W, C, device=dev, dtype=torch.bfloat16)
+    ms = timed(lambda: K.warp_forward(K.Sl(feat), flow, K.Sl(dense)), 20)
+    print(f"  ... into a dense tensor: {ms:.3f} ms")
+ms = timed(lambda: K.warp_backward(K.Sl(dout, C, 2 * C), K.Sl(feat), flow, K.Sl(dfeat), dflow, overwrite=True), 20)
+print(f"warp_backward (overwrite): {ms:.3f} ms")
+dfeat.zero_()
+ms = timed(lambda: K.warp_backward(K.Sl(dout, C, 2 * C), K.Sl(feat), flow, K.Sl(dfeat), dflow), 20)
+print(f"warp_backward (accumulate): {ms:.3f} ms")
