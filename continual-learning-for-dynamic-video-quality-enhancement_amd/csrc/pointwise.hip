@@ -901,12 +901,16 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
 // per-channel constants are loaded once.
 constexpr int EW_ITEMS = 4;
 
+// ALLB: every tensor is stored as bf16, known at compile time.  With run-time storage flags each ldx4 is a branch whose bf16 arm
+// converts - i.e. waits for - its own load, so a thread's 2 * EW_ITEMS loads run one after the other.
+template <bool ALLB>
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
     const float* __restrict__ x, int x_ld, int C, int c4_shift, unsigned group_items, long group_pix,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res, int res_ld, float* __restrict__ outA,
     int outA_ld, int outA_coff, long split_pix, float* __restrict__ outB, int outB_ld, int outB_coff,
-    int x_bf16, int out_bf16, int res_bf16) {
+    int x_bf16_, int out_bf16_, int res_bf16_) {
+    const int x_bf16 = ALLB ? 1 : x_bf16_, out_bf16 = ALLB ? 1 : out_bf16_, res_bf16 = ALLB ? 1 : res_bf16_;
     const int g = blockIdx.y;
     const int c4 = threadIdx.x & ((C >> 2) - 1);
     const float4 m = ld4(mean + g * C + 4 * c4), is = ld4(invstd + g * C + 4 * c4);
@@ -940,11 +944,12 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(
 }
 
 // backward pass 1: part[g][blk][2C] = {sum dyr, sum dyr*xhat}, dyr = dy * [bn(x) > 0]
+template <bool DYB, bool XB>                                  // storage types at compile time, see bn_apply_relu_kernel
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dy, int dy_ld, const float* __restrict__ x, int x_ld, int C,
     long group_pix, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int dy_bf16, int x_bf16,
-    float* __restrict__ part) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part) {
+    constexpr int dy_bf16 = DYB, x_bf16 = XB;
     __shared__ float4 buf[256];
     const int C4 = C >> 2;
     const int npl = 256 / C4;
@@ -1083,6 +1088,16 @@ static int blocks_for(long npix, int C);
 
 // BatchNorm backward, first half: the per-group sums  sum(g), sum(g xhat)  (g = dy masked by relu(bn(x)) > 0) in
 // sums[G][2C] inside the workspace, and dgamma / dbeta.  Used by nvq_bn_relu_backward and nvq_pw_bn_backward (pw_bwd.hip).
+static void launch_bn_bwd_reduce(dim3 grid, hipStream_t s, const float* dy, int dy_ld, const float* x, int x_ld, int C,
+                                 long group_pix, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 int dy_bf16, int x_bf16, float* part) {
+#define NVQ_BNR(D_, X_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<D_, X_>), grid, dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, \
+                                           mean, invstd, gamma, beta, part)
+    if (dy_bf16) { if (x_bf16) NVQ_BNR(true, true); else NVQ_BNR(true, false); }
+    else { if (x_bf16) NVQ_BNR(false, true); else NVQ_BNR(false, false); }
+#undef NVQ_BNR
+}
+
 int bn_backward_sums(const float* dy, int dy_ld, const float* x, int x_ld, int C, int G, long group_pix, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* workspace,
                      size_t workspace_bytes, int dy_bf16, int x_bf16, float** sums_out, hipStream_t s) {
@@ -1090,8 +1105,7 @@ int bn_backward_sums(const float* dy, int dy_ld, const float* x, int x_ld, int C
     const size_t part_floats = (size_t)G * nblk * 2 * C;
     if ((part_floats + (size_t)G * 2 * C) * sizeof(float) > workspace_bytes) { set_error("bn backward: workspace"); return NVQ_EWORKSPACE; }
     float* sums = workspace + part_floats;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, G), dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, mean,
-                       invstd, gamma, beta, dy_bf16, x_bf16, workspace);
+    launch_bn_bwd_reduce(dim3(nblk, G), s, dy, dy_ld, x, x_ld, C, group_pix, mean, invstd, gamma, beta, dy_bf16, x_bf16, workspace);
     int rc = check_launch("bn_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, sums, dgamma, dbeta, 0);
@@ -1326,10 +1340,12 @@ int nvq_bn_apply_relu(const float* x, int x_ld, int C, int N, int group_images, 
     int shift = 0;
     while ((1 << shift) < C / 4) ++shift;
     const unsigned items = (unsigned)(group_pix * (C / 4));
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(ceil_div((long)items, 256 * EW_ITEMS), G), dim3(256), 0, (hipStream_t)stream,
-                       x, x_ld, C, shift, items, group_pix, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld, outA_coff,
-                       (long)(split_images < N ? split_images : N) * H * W, outB, outB_ld, outB_coff, x_bf16, out_bf16,
-                       res_bf16);
+#define NVQ_BNA(A_)                                                                                                            \
+    hipLaunchKernelGGL(bn_apply_relu_kernel<A_>, dim3(ceil_div((long)items, 256 * EW_ITEMS), G), dim3(256), 0, (hipStream_t)stream, \
+                       x, x_ld, C, shift, items, group_pix, mean, invstd, gamma, beta, res, res_ld, outA, outA_ld, outA_coff,        \
+                       (long)(split_images < N ? split_images : N) * H * W, outB, outB_ld, outB_coff, x_bf16, out_bf16, res_bf16)
+    if (x_bf16 && out_bf16 && (res_bf16 || !res)) NVQ_BNA(true); else NVQ_BNA(false);
+#undef NVQ_BNA
     return check_launch("bn_apply_relu");
 }
 
@@ -1348,8 +1364,7 @@ int nvq_bn_relu_backward(const float* dy, int dy_ld, const float* x, int x_ld, i
     if ((part_floats + (size_t)G * 2 * C) * sizeof(float) > workspace_bytes) { set_error("bn_relu_backward: workspace"); return NVQ_EWORKSPACE; }
     float* sums = workspace + part_floats;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, G), dim3(256), 0, s, dy, dy_ld, x, x_ld, C, group_pix, mean,
-                       invstd, gamma, beta, dy_bf16, x_bf16, workspace);
+    launch_bn_bwd_reduce(dim3(nblk, G), s, dy, dy_ld, x, x_ld, C, group_pix, mean, invstd, gamma, beta, dy_bf16, x_bf16, workspace);
     int rc = check_launch("bn_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, workspace, nblk, C, G, sums,
