@@ -94,13 +94,15 @@ __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__
         st4(gap_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + 4 * c4, r);
 }
 
+template <bool ALLB>                                          // ALLB: aligned and daligned are bf16, known at compile time
 __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__ dweighted, int dweighted_ld,
                                                        const float* __restrict__ dgap_pix,
                                                        const float* __restrict__ aligned, int aligned_ld,
                                                        const float* __restrict__ attn, int attn_ld, int T, int C,
                                                        long HW, float* __restrict__ daligned, int daligned_ld,
                                                        float* __restrict__ dlogits, int dlogits_ld, long total,
-                                                       int aligned_bf16, int daligned_bf16) {
+                                                       int aligned_bf16_, int daligned_bf16_) {
+    const int aligned_bf16 = ALLB ? 1 : aligned_bf16_, daligned_bf16 = ALLB ? 1 : daligned_bf16_;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -470,9 +472,11 @@ int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dga
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && dlogits_ld >= T && attn_ld >= T, "tsum_backward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && dweighted_ld % 4 == 0 && daligned_ld % 4 == 0, "tsum_backward: ld");
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(tsum_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dweighted,
-                       dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, daligned,
-                       daligned_ld, dlogits, dlogits_ld, total, aligned_bf16, daligned_bf16);
+#define NVQ_TB(A_) hipLaunchKernelGGL(tsum_bwd_kernel<A_>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dweighted, \
+                                      dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, daligned,         \
+                                      daligned_ld, dlogits, dlogits_ld, total, aligned_bf16, daligned_bf16)
+    if (aligned_bf16 && daligned_bf16) NVQ_TB(true); else NVQ_TB(false);
+#undef NVQ_TB
     return check_launch("tsum_backward");
 }
 
