@@ -189,6 +189,149 @@ __global__ __launch_bounds__(M_T) void corr_fwd_mfma_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- forward, strip form (bf16-stored inputs)
+// The tile kernel above stages a 16 x 24-pixel halo for 8 x 16 pixels - three times its pixels - and does so with nothing
+// else to do: stage, barrier, compute, barrier, store.  Here a workgroup walks DOWN a strip of tiles (one 16-pixel column
+// block of one image, a segment of its tile rows): the halo rows live in LDS as a ring of 16 rows, a step fetches only the 8
+// new ones (1.5x the tile's pixels), and they - and the next tile's x1 operand - are fetched into registers while the current
+// tile is computed.  Row hy of tile ty sits in ring slot (hy + 8 (ty & 1)) & 15: the lower half of a tile's halo is the upper
+// half of the next one's.
+constexpr int MS_SEG = 4;                       // strips are cut into this many vertical segments (jobs = N x tilesX x MS_SEG)
+constexpr int MS_MAXWG = 512;                   // two workgroups per CU
+
+template <int C, bool OUT_BF16>
+__global__ __launch_bounds__(M_T) void corr_fwd_strip_kernel(const __bf16* __restrict__ x1, int x1_ld,
+                                                             const __bf16* __restrict__ x2, int x2_ld, int x2_images, int H,
+                                                             int W, int tilesX, int tilesY, int njobs,
+                                                             float* __restrict__ out, int out_ld) {
+    constexpr int YS = OUT_BF16 ? C + 8 : C + 16;
+    constexpr int KS = C / 32;
+    constexpr int PPP = C / 8;                   // 16-byte pieces per pixel
+    constexpr int HITEMS = 8 * MHW * PPP;        // pieces of 8 halo rows
+    constexpr int HPER = (HITEMS + M_T - 1) / M_T;
+    typedef typename std::conditional<OUT_BF16, __bf16, float>::type stage_t;
+    __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
+    __shared__ __attribute__((aligned(16))) stage_t stage[MT_H * MT_W * M_OSTR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, r = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    stage_t* srow = stage + (r * MT_W) * M_OSTR;
+    if (lane < 16) { srow[lane * M_OSTR + 81] = (stage_t)0.f; srow[lane * M_OSTR + 82] = (stage_t)0.f; srow[lane * M_OSTR + 83] = (stage_t)0.f; }
+    const float inv = 1.f / (float)C;
+    const int seg_rows = (tilesY + MS_SEG - 1) / MS_SEG;
+
+    m_u32x4 hv[HPER], xv[KS];
+    unsigned hokm = 0;
+    bool xin = false;
+    // halo rows 8 half .. 8 half + 7 of tile (n2, ty, tx) -> registers (clamped addresses; masked at commit)
+    auto fetch_rows = [&](int n2, int ty, int tx, int half) {
+        hokm = 0;
+        int tid_o = tid;                                      // (opaque copy: keeps the per-piece coordinates out of hoisted registers)
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int k = 0; k < HPER; ++k) {
+            const int item = tid_o + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hyl = hp / MHW, hx = hp - hyl * MHW;
+            const int gy = ty * MT_H + 8 * half + hyl - MD, gx = tx * MT_W + hx - MD;
+            const bool ok = item < HITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hokm |= (ok ? 1u : 0u) << k;
+            hv[k] = *reinterpret_cast<const m_u32x4*>(x2 + (ok ? ((size_t)(n2 * H + gy) * W + gx) * x2_ld + 8 * q : 0));
+        }
+    };
+    auto commit_rows = [&](int ty, int half) {
+#pragma unroll
+        for (int k = 0; k < HPER; ++k) {
+            const int item = tid + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hyl = hp / MHW, hx = hp - hyl * MHW;
+            const int slot = (8 * half + hyl + 8 * (ty & 1)) & 15;
+            if (item < HITEMS)
+                *reinterpret_cast<m_u32x4*>(ys + (slot * MHW + hx) * YS + 8 * q) = (hokm >> k) & 1 ? hv[k] : (m_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    // this lane's x1 operand of tile (n, ty, tx): pixel p of row r, channels 32 s + 8 g .. + 7
+    auto fetch_x1 = [&](int n, int ty, int tx) {
+        const int gy = ty * MT_H + r, gx = tx * MT_W + p;
+        xin = gy < H && gx < W;
+        const size_t off = xin ? ((size_t)(n * H + gy) * W + gx) * x1_ld : 0;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) xv[s2] = *reinterpret_cast<const m_u32x4*>(x1 + off + 32 * s2 + 8 * g);
+    };
+
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+        int jt = job;
+        const int seg = jt % MS_SEG; jt /= MS_SEG;
+        const int tx = jt % tilesX;
+        const int n = jt / tilesX;
+        const int n2 = n % x2_images;
+        const int ty0 = seg * seg_rows, ty1 = min(ty0 + seg_rows, tilesY);
+        if (ty0 >= ty1) continue;                             // (uniform)
+        // the segment's first tile: both halves of its halo
+        __syncthreads();                                      // the previous job's last reads of ys
+        fetch_rows(n2, ty0, tx, 0);
+        commit_rows(ty0, 0);
+        fetch_rows(n2, ty0, tx, 1);
+        fetch_x1(n, ty0, tx);
+        for (int ty = ty0; ty < ty1; ++ty) {
+            bf16x8 xb[KS];
+            commit_rows(ty, 1);
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) xb[s2] = __builtin_bit_cast(bf16x8, xin ? xv[s2] : (m_u32x4){0u, 0u, 0u, 0u});
+            __syncthreads();                                  // the tile's 16 halo rows are in the ring
+            if (ty + 1 < ty1) { fetch_rows(n2, ty + 1, tx, 1); fetch_x1(n, ty + 1, tx); }
+            const int rot = 8 * (ty & 1);
+#pragma unroll 1
+            for (int i = 0; i < MN; ++i) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    // A: m = halo pixel qb*8 + (lane & 15) of halo row r + i, k = channel
+                    const __bf16* arow = ys + ((((r + i) + rot) & 15) * MHW + qb * 8 + p) * YS + 8 * g;
+#pragma unroll
+                    for (int s2 = 0; s2 < KS; ++s2)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + 32 * s2), xb[s2], acc,
+                                                                      0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {             // D[m = 4g + e][n = p]: halo column q = qb*8 + m, displacement j = q - p
+                        const int m = 4 * g + e;
+                        const int j = qb * 8 + m - p;
+                        if (j >= 0 && j <= 8 && (qb == 0 || m >= 8)) srow[p * M_OSTR + i * MN + j] = (stage_t)(acc[e] * inv);
+                    }
+                }
+            }
+            // row r of the tile: 16 pixels x out_ld channels as whole 16-byte pieces (srow is this wave's own)
+            const int gy = ty * MT_H + r;
+            if (gy < H) {
+                if constexpr (OUT_BF16) {
+                    __bf16* o16 = reinterpret_cast<__bf16*>(out);
+                    const int ppp = out_ld / 8;
+                    for (int item = lane; item < MT_W * ppp; item += 64) {
+                        const int px = item / ppp, q = item - px * ppp;
+                        if (tx * MT_W + px >= W) continue;
+                        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                        u2 lo = {0u, 0u}, hi = {0u, 0u};
+                        if (8 * q < M_OSTR) lo = *reinterpret_cast<const u2*>(srow + px * M_OSTR + 8 * q);
+                        if (8 * q + 4 < M_OSTR) hi = *reinterpret_cast<const u2*>(srow + px * M_OSTR + 8 * q + 4);
+                        *reinterpret_cast<m_u32x4*>(o16 + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 8 * q) =
+                            (m_u32x4){lo[0], lo[1], hi[0], hi[1]};
+                    }
+                } else {
+                    const int ppp = out_ld / 4;
+                    for (int item = lane; item < MT_W * ppp; item += 64) {
+                        const int px = item / ppp, q = item - px * ppp;
+                        if (tx * MT_W + px >= W) continue;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (4 * q < M_OSTR) v = ld4(srow + px * M_OSTR + 4 * q);
+                        st4(out + ((size_t)(n * H + gy) * W + tx * MT_W + px) * out_ld + 4 * q, v);
+                    }
+                }
+            }
+            __syncthreads();                                  // everyone is done with the rows the next commit replaces
+        }
+    }
+}
+
 // ---------------------------------------------------------------- gradients
 // WHICH == 1: dx[n,p,c] (+)= (1/C) sum_d dcorr[n,p,d]          * other[n % oi, p + off(d), c]
 // WHICH == 2: dx[n,q,c] (+)= (1/C) sum_d dcorr[n,q - off(d),d] * other[n,      q - off(d), c]
@@ -337,6 +480,17 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
     NVQ_REQUIRE(!in_bf16 || (x1_ld % 8 == 0 && x2_ld % 8 == 0), "correlation_forward(bf16): bf16 inputs need ld %% 8 == 0");
     NVQ_REQUIRE(out_ld >= 84 && out_ld % (out_bf16 ? 8 : 4) == 0, "correlation_forward(bf16): out_ld %d", out_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
+    if (in_bf16) {                                            // bf16-stored features: the strip form (1.12 -> 1.03 ms at 16 x 540 x 960)
+        const int njobs = N * tilesX * MS_SEG;
+        int nwg = njobs < MS_MAXWG ? njobs : MS_MAXWG;
+#define NVQ_CS(CC, OB) \
+    hipLaunchKernelGGL((corr_fwd_strip_kernel<CC, OB>), dim3(nwg), dim3(M_T), 0, s, reinterpret_cast<const __bf16*>(x1), x1_ld, \
+                       reinterpret_cast<const __bf16*>(x2), x2_ld, x2_images, H, W, tilesX, tilesY, njobs, out, out_ld)
+        if (C == 64) { if (out_bf16) NVQ_CS(64, true); else NVQ_CS(64, false); }
+        else { if (out_bf16) NVQ_CS(32, true); else NVQ_CS(32, false); }
+#undef NVQ_CS
+        return check_launch("correlation_forward(bf16, strip)");
+    }
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CF(CC, OB) \
     hipLaunchKernelGGL((corr_fwd_mfma_kernel<CC, OB>), grid, dim3(M_T), 0, s, x1, x1_ld, x2, x2_ld, x2_images, H, W, tilesX, tilesY, out, out_ld, in_bf16)

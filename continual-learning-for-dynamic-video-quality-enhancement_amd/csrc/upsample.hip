@@ -78,44 +78,61 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(float* __restrict__ 
         for (int k = C * s * s; k < u_ld; ++k) up[k] = 0.f;
 }
 
-// one thread per LR pixel
+// one thread per LR pixel.  S > 0 (S = 2, 3, 4 with RGB frames, du_ld = pad4(3 S^2), aligned pointers): the pixel's S x S block
+// of every channel is read row by row as 8- / 16-byte loads (S = 2 / 4; scalar for S = 3) and its 3 S^2 values leave as
+// 16-byte stores - one 4-byte store per value at a du_ld * 4-byte lane stride ran at 0.9 TB/s.  S = 0: any shape.
+template <int S>
 __global__ __launch_bounds__(256) void shuffle_clamp_bwd_kernel(const float* __restrict__ dout,
                                                                  const uint8_t* __restrict__ pass, int Cimg, int H,
                                                                  int W, int s, float* __restrict__ du, int du_ld,
-                                                                 long total, int fast) {
+                                                                 long total) {
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const long lrow = idiv(gid, W, total);
     const int w = (int)(gid - lrow * W);
     const int b = (int)idiv(lrow, H, total);
     const int h = (int)(lrow - (long)b * H);
-    const int OW = W * s, OH = H * s;
     float* dp = du + (size_t)gid * du_ld;
-    const int K = Cimg * s * s;
-    if (fast) {                                               // s == 2, Cimg == 3, du_ld == 12, aligned pointers
-        // the 2x RGB case: the pixel's 2 x 2 block of every channel as two 8-byte loads, its 12 values as three 16-byte stores
-        // (one 4-byte store per value at a 48-byte lane stride ran at 0.9 TB/s)
-        float v[12];
+    if constexpr (S > 0) {
+        constexpr int K = 3 * S * S, KP = (K + 3) / 4 * 4;
+        const int OW = W * S, OH = H * S;
+        float v[KP];
+#pragma unroll
+        for (int k = K; k < KP; ++k) v[k] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const size_t o = ((size_t)(b * 3 + c) * OH + h * 2 + i) * OW + w * 2;      // even: 8-byte / 2-byte aligned
-                const float2 d2 = *reinterpret_cast<const float2*>(dout + o);
-                const uchar2 p2 = *reinterpret_cast<const uchar2*>(pass + o);
-                v[c * 4 + i * 2] = p2.x ? d2.x : 0.f;
-                v[c * 4 + i * 2 + 1] = p2.y ? d2.y : 0.f;
+            for (int i = 0; i < S; ++i) {
+                const size_t o = ((size_t)(b * 3 + c) * OH + h * S + i) * OW + w * S;
+                float d[S];
+                uint8_t m[S];
+                if constexpr (S == 2) {
+                    const float2 d2 = *reinterpret_cast<const float2*>(dout + o);
+                    const uchar2 p2 = *reinterpret_cast<const uchar2*>(pass + o);
+                    d[0] = d2.x; d[1] = d2.y; m[0] = p2.x; m[1] = p2.y;
+                } else if constexpr (S == 4) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(dout + o);
+                    const uchar4 p4 = *reinterpret_cast<const uchar4*>(pass + o);
+                    d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w; m[0] = p4.x; m[1] = p4.y; m[2] = p4.z; m[3] = p4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < S; ++j) { d[j] = dout[o + j]; m[j] = pass[o + j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < S; ++j) v[c * S * S + i * S + j] = m[j] ? d[j] : 0.f;
             }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) st4(dp + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
-        return;
+        for (int q = 0; q < KP / 4; ++q) st4(dp + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
+    } else {
+        const int OW = W * s, OH = H * s;
+        const int K = Cimg * s * s;
+        for (int k = 0; k < K; ++k) {
+            const int c = k / (s * s), r = k - c * s * s, i = r / s, j = r - i * s;
+            const size_t o = ((size_t)(b * Cimg + c) * OH + h * s + i) * OW + w * s + j;
+            dp[k] = pass[o] ? dout[o] : 0.f;
+        }
+        for (int k = K; k < du_ld; ++k) dp[k] = 0.f;
     }
-    for (int k = 0; k < K; ++k) {
-        const int c = k / (s * s), r = k - c * s * s, i = r / s, j = r - i * s;
-        const size_t o = ((size_t)(b * Cimg + c) * OH + h * s + i) * OW + w * s + j;
-        dp[k] = pass[o] ? dout[o] : 0.f;
-    }
-    for (int k = K; k < du_ld; ++k) dp[k] = 0.f;
 }
 
 // out = strength * sr + (1 - strength) * bicubic(frames[:, t_center])   (EnhancementEngine strength < 1 blend)
@@ -176,10 +193,12 @@ int nvq_shuffle_clamp_backward(const float* dout, const uint8_t* pass, int B, in
                                float* du, int du_ld, void* stream) {
     NVQ_REQUIRE(s >= 1 && s <= 8 && du_ld >= Cimg * s * s, "shuffle_clamp_backward: args");
     const long total = (long)B * H * W;
-    const int fast = s == 2 && Cimg == 3 && du_ld == 12 && aligned16(du) && (reinterpret_cast<uintptr_t>(dout) & 7) == 0 &&
-                     (reinterpret_cast<uintptr_t>(pass) & 1) == 0;
-    hipLaunchKernelGGL(shuffle_clamp_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout,
-                       pass, Cimg, H, W, s, du, du_ld, total, fast);
+    const bool fast = Cimg == 3 && s >= 2 && s <= 4 && du_ld == (3 * s * s + 3) / 4 * 4 && aligned16(du) &&
+                      (reinterpret_cast<uintptr_t>(dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(pass) & 3) == 0;
+#define NVQ_SCB(S_) hipLaunchKernelGGL(shuffle_clamp_bwd_kernel<S_>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, \
+                                       dout, pass, Cimg, H, W, s, du, du_ld, total)
+    if (fast && s == 2) NVQ_SCB(2); else if (fast && s == 3) NVQ_SCB(3); else if (fast && s == 4) NVQ_SCB(4); else NVQ_SCB(0);
+#undef NVQ_SCB
     return check_launch("shuffle_clamp_backward");
 }
 

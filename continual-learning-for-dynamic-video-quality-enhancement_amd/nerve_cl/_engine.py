@@ -176,9 +176,11 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
     # ---- motion: correlation -> flow net -> warp, the T-1 reference frames batched
     if NO:
-        # bf16 mode: correlation on the matrix cores, stored as bf16 with a 128-channel (256-B) pixel stride
+        # bf16 mode: correlation on the matrix cores, stored as bf16 with the same 96-channel pixel stride (192 B: the 16 pixels a
+        # workgroup writes per row are 24 whole 128-B lines, and the flow net's three 32-channel chunks are 64-B pieces that never
+        # straddle a line; a 128-channel stride moved a third more bytes through six passes for the same step time)
         corr_bf16 = act_dtype == torch.bfloat16 and F in (32, 64)
-        corr = _new(dev, NO, H, W, 128 if corr_bf16 else CORR_LD, dtype=act_dtype if corr_bf16 else torch.float32)
+        corr = _new(dev, NO, H, W, CORR_LD, dtype=act_dtype if corr_bf16 else torch.float32)
         K.correlation_forward(Sl(feat_oth), center, corr, math=math)
         chans = [81, 128, 64, 32, 2]
         x = Sl(corr, CORR_LD, 0)
@@ -430,8 +432,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
                                mask_c1=chans[li], math=math)
             else:
-                # gradient of the correlation volume: the bf16 volume's 128-channel rows are written whole (zeros behind the
-                # 81 real channels) - a row of 84 channels would leave its second 128-B line half written (a fill read)
+                # gradient of the correlation volume: the bf16 volume's 96-channel rows are written whole (zeros behind the
+                # 81 real channels) - a row of 84 channels would leave lines half written (fill reads)
                 full = dx_t.shape[-1] if dx_t.dtype == torch.bfloat16 else K.pad4(chans[li])
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, cout_store=full, math=math)
             dy_t, dy_c = dx_t, chans[li]

@@ -498,6 +498,10 @@ def test_shuffle_bicubic_clamp(K, s, B, T, H, W):
     assert diff.max().item() < 1e-6
     if Up > 3 * s * s:
         assert du[..., 3 * s * s:].abs().max().item() == 0
+    # the same through the any-shape kernel (a wider du row is not the vectorised kernels' layout)
+    du_wide = torch.full((B, H, W, Up + 4), 4.0, device="cuda")
+    K.shuffle_clamp_backward(dy.cuda(), pm, s, du_wide)
+    assert torch.equal(du_wide[..., :Up], du) and du_wide[..., Up:].abs().max().item() == 0
 
 
 # ----------------------------------------------------------------------------- helpers / EWC
