@@ -66,14 +66,17 @@ __device__ __forceinline__ float4 cpar(const float* __restrict__ p, int c, int C
     return make_float4(p[c], c + 1 < C ? p[c + 1] : 0.f, c + 2 < C ? p[c + 2] : 0.f, c + 3 < C ? p[c + 3] : 0.f);
 }
 
-template <int MODE>
+// BF: the tensors' storage type at compile time (as a run-time flag every ldx4 is a branch that waits for its own load: the
+// two or three loads of a trip ran one after the other)
+template <int MODE, bool BF>
 __global__ __launch_bounds__(256) void bn2_partial_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                           const float* __restrict__ dy, int dy_ld,
                                                           const float* __restrict__ res, int res_ld,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int relu, float* __restrict__ gout, int gout_ld,
-                                                          float* __restrict__ part, int bf) {
+                                                          float* __restrict__ part) {
+    constexpr int bf = BF;
     __shared__ float red[256 * 8];
     const int G4 = (C + 3) >> 2;
     const int rows = 256 / G4;                       // pixel rows handled per iteration (G4 <= 256)
@@ -177,11 +180,13 @@ __global__ __launch_bounds__(256) void bn2_eval_stats_kernel(const float* __rest
 
 // y = bn(x) (+ res) (ReLU); channels [C, out_ld) written as 0.  A thread owns one 4-channel group (its parameters are
 // loaded once) and walks the workgroup's pixel range, 256 / G4 pixels per step.
+template <bool BF>
 __global__ __launch_bounds__(256) void bn2_apply_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ res, int res_ld, int relu,
-                                                        float* __restrict__ out, int out_ld, int bf) {
+                                                        float* __restrict__ out, int out_ld) {
+    constexpr int bf = BF;
     const int G4 = out_ld >> 2;                      // groups written per pixel (padding groups get zeros)
     const int rows = 256 / G4;
     const int g = threadIdx.x % G4, row = threadIdx.x / G4;
@@ -229,13 +234,15 @@ __global__ __launch_bounds__(256) void bn2_bwd_final_kernel(const float* __restr
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))   (training)   |   gamma * invstd * g   (eval)
 // g is read from `g` when given (written by the partial pass), else recomputed from dy and the ReLU of bn(x).
 // Same thread mapping as bn2_apply_kernel.
+template <bool BF>
 __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restrict__ x, int x_ld, int C, long npix,
                                                             const float* __restrict__ dy, int dy_ld,
                                                             const float* __restrict__ g, int g_ld,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ sums, int relu, int training,
-                                                            float* __restrict__ dx, int dx_ld, int bf) {
+                                                            float* __restrict__ dx, int dx_ld) {
+    constexpr int bf = BF;
     const int G4 = dx_ld >> 2;
     const int rows = 256 / G4;
     const int gi = threadIdx.x % G4, row = threadIdx.x / G4;
@@ -855,8 +862,10 @@ int nvq_bn2_stats(const float* x, int x_ld, int C, long npix, float eps, float m
     NVQ_REQUIRE(workspace_bytes >= nvq_bn2_workspace_bytes(C), "bn2_stats: workspace");
     hipStream_t s = (hipStream_t)stream;
     const int nb = bn2_nblk(npix);
-    hipLaunchKernelGGL(bn2_partial_kernel<0>, dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                       nullptr, nullptr, 0, nullptr, 0, workspace, bf16);
+#define NVQ_B2P(B_) hipLaunchKernelGGL((bn2_partial_kernel<0, B_>), dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, nullptr, 0, nullptr, 0, \
+                                       nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, workspace)
+    if (bf16) NVQ_B2P(true); else NVQ_B2P(false);
+#undef NVQ_B2P
     int rc = check_launch("bn2_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_stats_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, npix, eps, momentum, mean,
@@ -877,8 +886,10 @@ int nvq_bn2_apply(const float* x, int x_ld, int C, long npix, const float* mean,
                     (!res || (((C + 3) & ~3) <= res_ld && res_ld % 4 == 0 && aligned16(res))),
                 "bn2_apply: C %d ld %d/%d", C, x_ld, out_ld);
     NVQ_REQUIRE(out_ld <= 1024, "bn2_apply: ld %d", out_ld);
-    hipLaunchKernelGGL(bn2_apply_kernel, dim3(bn2_ew_blocks(npix, out_ld)), dim3(256), 0, (hipStream_t)stream, x, x_ld, C, npix,
-                       mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld, bf16);
+#define NVQ_B2A(B_) hipLaunchKernelGGL(bn2_apply_kernel<B_>, dim3(bn2_ew_blocks(npix, out_ld)), dim3(256), 0, (hipStream_t)stream, x, \
+                                       x_ld, C, npix, mean, invstd, gamma, beta, res, res_ld, relu, out, out_ld)
+    if (bf16) NVQ_B2A(true); else NVQ_B2A(false);
+#undef NVQ_B2A
     return check_launch("bn2_apply");
 }
 
@@ -895,16 +906,20 @@ int nvq_bn2_backward(const float* dy, int dy_ld, const float* x, int x_ld, int C
     hipStream_t s = (hipStream_t)stream;
     const int nb = bn2_nblk(npix);
     float* sums = workspace + (size_t)BN2_MAXBLK * 2 * C;
-    hipLaunchKernelGGL(bn2_partial_kernel<1>, dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld, res, res_ld, mean, invstd,
-                       gamma, beta, relu, dres, dres_ld, workspace, bf16);
+#define NVQ_B2P(B_) hipLaunchKernelGGL((bn2_partial_kernel<1, B_>), dim3(nb), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld, res, res_ld, \
+                                       mean, invstd, gamma, beta, relu, dres, dres_ld, workspace)
+    if (bf16) NVQ_B2P(true); else NVQ_B2P(false);
+#undef NVQ_B2P
     int rc = check_launch("bn2_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn2_bwd_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, workspace, nb, C, sums, dgamma, dbeta);
     rc = check_launch("bn2_bwd_final");
     if (rc) return rc;
     NVQ_REQUIRE(dx_ld <= 1024, "bn2_backward: ld %d", dx_ld);
-    hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(bn2_ew_blocks(npix, dx_ld)), dim3(256), 0, s, x, x_ld, C, npix, dy, dy_ld,
-                       dres, dres_ld, mean, invstd, gamma, beta, sums, relu, training, dx, dx_ld, bf16);
+#define NVQ_B2B(B_) hipLaunchKernelGGL(bn2_bwd_apply_kernel<B_>, dim3(bn2_ew_blocks(npix, dx_ld)), dim3(256), 0, s, x, x_ld, C, npix, dy, \
+                                       dy_ld, dres, dres_ld, mean, invstd, gamma, beta, sums, relu, training, dx, dx_ld)
+    if (bf16) NVQ_B2B(true); else NVQ_B2B(false);
+#undef NVQ_B2B
     return check_launch("bn2_bwd_apply");
 }
 
