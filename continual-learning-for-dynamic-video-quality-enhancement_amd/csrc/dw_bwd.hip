@@ -15,6 +15,9 @@
 #include "conv_common.h"
 
 namespace nvq {
+
+int bn_bwd_finalize_launch(const float* part, int nblk, int C, int G, float* sums, float* dgamma, float* dbeta, hipStream_t s);  // pointwise.hip
+
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -39,6 +42,7 @@ struct DwBwdArgs {
     const float* add; int add_ld;                            // epilogue (HAS_EPI): fp32 addend, bf16 mask
     const __bf16* mask; int mask_ld;
     float* part;               // [G * gridDim.x][64 * 9]
+    float* part2;              // STATS: [G][gridDim.x][2][64]
     int H, W, tilesX, tilesY, group_images, tiles_per_group;
 };
 
@@ -47,8 +51,13 @@ __device__ __forceinline__ float4 unpack4(u32x2 v) {
                        __uint_as_float(v[1] & 0xffff0000u));
 }
 
-template <bool HAS_BN, bool HAS_EPI>
+// STATS (with HAS_BN): the kernel also leaves the BatchNorm-backward sums of the input transform's BatchNorm - per channel
+// sum g and sum g xhat over the group, g = dx where relu(bn(x)) > 0 - as per-workgroup partials: the kernel holds both operands
+// (x is the BatchNorm input, dx its activation's gradient), so the separate reduce pass over them (bn_bwd_reduce) is not needed.
+// x is then staged RAW and the transform applied by the thread that uses the value (which also needs xhat).
+template <bool HAS_BN, bool HAS_EPI, bool STATS>
 __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
+    static_assert(!STATS || HAS_BN, "the sums belong to the input transform");
     __shared__ __attribute__((aligned(16))) __bf16 gs[FNPIX * FC];        // dd halo tile, 128 B per pixel
     __shared__ __attribute__((aligned(16))) __bf16 xs[FH * FW * FC];      // x' tile
     __shared__ __attribute__((aligned(16))) float cst[4][FC];             // mean, invstd, gamma, beta of the input transform
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
         wacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);          // weight gradient of tap 8 - t
     }
 
+    float4 bs1 = make_float4(0.f, 0.f, 0.f, 0.f), bs2 = bs1;  // STATS: sum g, sum g xhat of this thread's 4 channels
     const int tiles_per_image = a.tilesX * a.tilesY;
     u32x4 v[PER], xv[XPER];
     unsigned okm = 0, xokm = 0;
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
             for (int e = 0; e < 4; ++e) o[e] = (okm >> k) & 1 ? v[k][e] : 0u;
             if (item < FNPIX * 8) *reinterpret_cast<u32x4*>(gs + (item >> 3) * FC + 8 * (item & 7)) = o;
         }
-        if constexpr (HAS_BN) {
+        if constexpr (HAS_BN && !STATS) {
             // same expression and the same single bf16 rounding as bn_apply_relu_kernel (pointwise.hip)
             const int c0 = 8 * (tid & 7);
             float m[8], is[8], ga[8], be[8];
@@ -175,12 +185,24 @@ __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
             const int gx = tx * FW + x;
             float4 a0 = z4, a1 = z4, a2 = z4;                  // dx' of rows rr, rr - 1, rr - 2
             float4 X0 = z4, X1 = z4, X2 = z4;                  // x' of rows rr, rr - 1, rr - 2
+            constexpr int RUK = STATS ? 2 : RU;                // (the sums' registers: five unrolled rows spill)
 #pragma unroll 1
-            for (int r0 = 0; r0 < FH + 2; r0 += RU)
+            for (int r0 = 0; r0 < FH + 2; r0 += RUK)
 #pragma unroll
-            for (int ri = 0; ri < RU; ++ri) {
+            for (int ri = 0; ri < RUK; ++ri) {
                 const int rr = r0 + ri;
-                if (rr < FH) X0 = unpack4(*reinterpret_cast<const u32x2*>(xs + (rr * FW + x) * FC + 4 * c4));
+                if (rr < FH) {
+                    X0 = unpack4(*reinterpret_cast<const u32x2*>(xs + (rr * FW + x) * FC + 4 * c4));
+                    if constexpr (STATS) {                    // raw x -> relu(bn(x)), the expression and rounding of the staging form
+                        const bool ok = ty * FH + rr < a.H && gx < a.W;
+                        const float4 m = *reinterpret_cast<const float4*>(&cst[0][4 * c4]), is = *reinterpret_cast<const float4*>(&cst[1][4 * c4]);
+                        const float4 ga = *reinterpret_cast<const float4*>(&cst[2][4 * c4]), be = *reinterpret_cast<const float4*>(&cst[3][4 * c4]);
+                        X0.x = ok ? (float)(__bf16)fmaxf((X0.x - m.x) * is.x * ga.x + be.x, 0.f) : 0.f;
+                        X0.y = ok ? (float)(__bf16)fmaxf((X0.y - m.y) * is.y * ga.y + be.y, 0.f) : 0.f;
+                        X0.z = ok ? (float)(__bf16)fmaxf((X0.z - m.z) * is.z * ga.z + be.z, 0.f) : 0.f;
+                        X0.w = ok ? (float)(__bf16)fmaxf((X0.w - m.w) * is.w * ga.w + be.w, 0.f) : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     const float4 vv = unpack4(*reinterpret_cast<const u32x2*>(gs + (rr * FHW + x + b) * FC + 4 * c4));
@@ -218,7 +240,19 @@ __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
                                 if (!(mk.w > 0.f)) o.w = 0.f;
                             }
                         }
-                        *reinterpret_cast<bf16x4*>(a.dx + pix * a.dx_ld + 4 * c4) = (bf16x4){(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+                        const bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+                        *reinterpret_cast<bf16x4*>(a.dx + pix * a.dx_ld + 4 * c4) = ob;
+                        if constexpr (STATS) {
+                            // g = the STORED gradient where the activation is positive (X2 = relu(bn(x)) of this pixel); xhat from
+                            // the raw x of the tile
+                            const float4 raw = unpack4(*reinterpret_cast<const u32x2*>(xs + ((rr - 2) * FW + x) * FC + 4 * c4));
+                            const float4 m = *reinterpret_cast<const float4*>(&cst[0][4 * c4]), is = *reinterpret_cast<const float4*>(&cst[1][4 * c4]);
+                            const float g0 = X2.x > 0.f ? (float)ob[0] : 0.f, g1 = X2.y > 0.f ? (float)ob[1] : 0.f;
+                            const float g2 = X2.z > 0.f ? (float)ob[2] : 0.f, g3 = X2.w > 0.f ? (float)ob[3] : 0.f;
+                            bs1.x += g0; bs1.y += g1; bs1.z += g2; bs1.w += g3;
+                            bs2.x += g0 * ((raw.x - m.x) * is.x); bs2.y += g1 * ((raw.y - m.y) * is.y);
+                            bs2.z += g2 * ((raw.z - m.z) * is.z); bs2.w += g3 * ((raw.w - m.w) * is.w);
+                        }
                     }
                 }
                 a2 = a1; a1 = a0; a0 = z4;
@@ -250,6 +284,22 @@ __global__ __launch_bounds__(FT, 2) void dw_bwd_kernel(const DwBwdArgs a) {
                         red[(3 * 16 + ci) * 36 + k];
         prow[(4 * ci + (k & 3)) * 9 + (k >> 2)] = s;
     }
+    if constexpr (STATS) {                                    // the same reduction for the 2 x 4 BatchNorm sums per thread
+        __syncthreads();
+        float sv[8] = {bs1.x, bs1.y, bs1.z, bs1.w, bs2.x, bs2.y, bs2.z, bs2.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sv[e] += __shfl_xor(sv[e], 16, 64);
+            sv[e] += __shfl_xor(sv[e], 32, 64);
+            if (lane < 16) red[(wave * 16 + lane) * 8 + e] = sv[e];
+        }
+        __syncthreads();
+        if (tid < 2 * FC) {
+            const int which = tid >> 6, c = tid & 63, ci = c >> 2, k = which * 4 + (c & 3);
+            a.part2[((size_t)g * gridDim.x + blockIdx.x) * 2 * FC + tid] =
+                red[(0 * 16 + ci) * 8 + k] + red[(1 * 16 + ci) * 8 + k] + red[(2 * 16 + ci) * 8 + k] + red[(3 * 16 + ci) * 8 + k];
+        }
+    }
 }
 
 }  // namespace
@@ -259,7 +309,10 @@ using namespace nvq;
 
 extern "C" int nvq_dwconv_backward(const float* x, int x_ld, const nvq_bn_input* bn, const float* dy, int dy_ld,
                                    const float* weight, float* dx, int dx_ld, const nvq_dw_epilogue* epi, int N, int H, int W,
-                                   float* dweight, float* workspace, size_t workspace_bytes, void* stream) {
+                                   float* dweight, float* bn_sums, float* bn_dgamma, float* bn_dbeta, float* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    NVQ_REQUIRE(!bn_sums || (bn && !epi && bn_dgamma && bn_dbeta),
+                "dwconv_backward: the BatchNorm-backward sums need the input transform (and its dgamma / dbeta), no epilogue");
     NVQ_REQUIRE(!bn || (bn->group_images > 0 && N % bn->group_images == 0 && N / bn->group_images <= NVQ_MAX_T),
                 "dwconv_backward: groups of the input transform");
     NVQ_REQUIRE(x_ld % 8 == 0 && dy_ld % 8 == 0 && dx_ld % 8 == 0 && x_ld >= FC && dy_ld >= FC && dx_ld >= FC && aligned16(x) &&
@@ -276,20 +329,24 @@ extern "C" int nvq_dwconv_backward(const float* x, int x_ld, const nvq_bn_input*
     int nwg = FMAXWG / G;
     if (nwg > tpg) nwg = tpg;
     if (nwg >= 8) nwg &= ~7;                                  // multiple of the XCD count, see xcd_tile()
-    if ((size_t)G * nwg * FC * 9 * sizeof(float) > workspace_bytes) { set_error("dwconv_backward: workspace"); return NVQ_EWORKSPACE; }
+    const size_t part_floats = (size_t)G * nwg * FC * 9, part2_floats = bn_sums ? (size_t)G * nwg * 2 * FC : 0;
+    if ((part_floats + part2_floats) * sizeof(float) > workspace_bytes) { set_error("dwconv_backward: workspace"); return NVQ_EWORKSPACE; }
     DwBwdArgs a{reinterpret_cast<const __bf16*>(x), x_ld, reinterpret_cast<const __bf16*>(dy), dy_ld, weight,
                 reinterpret_cast<__bf16*>(dx), dx_ld, bn ? bn->mean : nullptr, bn ? bn->invstd : nullptr,
                 bn ? bn->gamma : nullptr, bn ? bn->beta : nullptr, epi ? epi->add : nullptr, epi ? epi->add_ld : 0,
-                epi ? reinterpret_cast<const __bf16*>(epi->mask) : nullptr, epi ? epi->mask_ld : 0, workspace, H, W, tilesX,
-                tilesY, group_images, tpg};
+                epi ? reinterpret_cast<const __bf16*>(epi->mask) : nullptr, epi ? epi->mask_ld : 0, workspace,
+                workspace + part_floats, H, W, tilesX, tilesY, group_images, tpg};
     hipStream_t s = (hipStream_t)stream;
-#define NVQ_DWBWD(B_, E_) hipLaunchKernelGGL((dw_bwd_kernel<B_, E_>), dim3(nwg, G), dim3(FT), 0, s, a)
-    if (bn && epi) NVQ_DWBWD(true, true);
-    else if (bn) NVQ_DWBWD(true, false);
-    else if (epi) NVQ_DWBWD(false, true);
-    else NVQ_DWBWD(false, false);
+#define NVQ_DWBWD(B_, E_, S_) hipLaunchKernelGGL((dw_bwd_kernel<B_, E_, S_>), dim3(nwg, G), dim3(FT), 0, s, a)
+    if (bn_sums) NVQ_DWBWD(true, false, true);
+    else if (bn && epi) NVQ_DWBWD(true, true, false);
+    else if (bn) NVQ_DWBWD(true, false, false);
+    else if (epi) NVQ_DWBWD(false, true, false);
+    else NVQ_DWBWD(false, false, false);
 #undef NVQ_DWBWD
     int rc = check_launch("dwconv_backward");
     if (rc) return rc;
-    return launch_reduce_partials(workspace, G * nwg, FC * 9, 1.f, dweight, 0, s);
+    rc = launch_reduce_partials(workspace, G * nwg, FC * 9, 1.f, dweight, 0, s);
+    if (rc || !bn_sums) return rc;
+    return bn_bwd_finalize_launch(workspace + part_floats, nwg, FC, G, bn_sums, bn_dgamma, bn_dbeta, s);
 }

@@ -1113,6 +1113,13 @@ int bn_backward_sums(const float* dy, int dy_ld, const float* x, int x_ld, int C
     return check_launch("bn_bwd_finalize");
 }
 
+// part[g][blk][2C] = {sum g, sum g xhat} -> sums[g][2C], dgamma, dbeta (overwritten).  Shared with dw_bwd.hip, whose kernel can
+// produce these partials itself.
+int bn_bwd_finalize_launch(const float* part, int nblk, int C, int G, float* sums, float* dgamma, float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, nblk, C, G, sums, dgamma, dbeta, 0);
+    return check_launch("bn_bwd_finalize");
+}
+
 // part[g][blk][2C] = {sum, sum of squares} -> mean / invstd per group; the groups are folded into the running statistics in
 // `order_host` (identity when null).  Shared by nvq_bn_stats and the fused forward kernel (dwpw_fwd.hip).
 int bn_finalize_launch(const float* part, int nblk, int C, int G, long group_pix, float eps, float momentum,

@@ -230,8 +230,8 @@ using namespace nvq;
 extern "C" int nvq_pw_bn_backward(const float* dy, int dy_ld, int dy_bf16, const float* p, int p_ld, const float* d, int d_ld,
                                   int N, int group_images, int H, int W, const float* mean, const float* invstd,
                                   const float* gamma, const float* beta, int training, const float* weight, float* dd,
-                                  int dd_ld, float* dgamma, float* dbeta, float* dweight, float* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  int dd_ld, float* dgamma, float* dbeta, float* dweight, const float* sums_in,
+                                  float* workspace, size_t workspace_bytes, void* stream) {
     NVQ_REQUIRE(group_images > 0 && N % group_images == 0 && N / group_images <= NVQ_MAX_T, "pw_bn_backward: groups");
     NVQ_REQUIRE(p_ld % 8 == 0 && d_ld % 8 == 0 && dd_ld % 8 == 0 && dy_ld % 8 == 0 && p_ld >= PC && d_ld >= PC && dd_ld >= PC &&
                     dy_ld >= PC && aligned16(p) && aligned16(d) && aligned16(dd) && aligned16(dy),
@@ -245,11 +245,14 @@ extern "C" int nvq_pw_bn_backward(const float* dy, int dy_ld, int dy_bf16, const
     int nsplit = ntiles < WGRAD_MAX_WG ? (int)ntiles : WGRAD_MAX_WG;
     const size_t part_floats = (size_t)nsplit * 4 * WG_C * WG_C;
     NVQ_REQUIRE(part_floats * sizeof(float) < workspace_bytes, "pw_bn_backward: workspace");
-    float* sums = nullptr;
-    // BatchNorm sums (and dgamma / dbeta) first: two-stage reduction in the workspace behind the weight-gradient slabs
-    int rc = bn_backward_sums(dy, dy_ld, p, p_ld, PC, G, group_pix, mean, invstd, gamma, beta, dgamma, dbeta, workspace + part_floats,
+    float* sums = const_cast<float*>(sums_in);
+    int rc = NVQ_OK;
+    if (!sums_in) {
+        // BatchNorm sums (and dgamma / dbeta) first: two-stage reduction in the workspace behind the weight-gradient slabs
+        rc = bn_backward_sums(dy, dy_ld, p, p_ld, PC, G, group_pix, mean, invstd, gamma, beta, dgamma, dbeta, workspace + part_floats,
                               workspace_bytes - part_floats * sizeof(float), dy_bf16, 1, &sums, s);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     PwBwdArgs a{dy, dy_ld, reinterpret_cast<const __bf16*>(p), p_ld, reinterpret_cast<const __bf16*>(d), d_ld, mean, invstd, gamma,
                 beta, sums, weight, reinterpret_cast<__bf16*>(dd), dd_ld, workspace, group_pix, G, training, tpg, (int)ntiles,
                 1.f / (float)group_pix};

@@ -449,6 +449,10 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     # ---- feature extractor (all frames batched)
     _capture("dfeat_all", dfeat_all)
     dcur = dfeat_all
+    bn_sums = None                    # BatchNorm-backward sums of layer k, when the depthwise backward of layer k + 1 left them
+    # (built and measured, off by default: with the sums in it the depthwise backward only fits its registers with two instead
+    # of five unrolled rows, and the step is 0.2 ms SLOWER than with the separate 0.54 ms reduce passes it replaces)
+    fuse_sums = os.environ.get("NVQ_FUSED_BN_SUMS", "0") != "0"
     for k in (2, 1, 0):
         pre = f"feature_extractor.body.{k}."
         dd = _new(dev, NI, H, W, F, dtype=act_dtype)
@@ -459,7 +463,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             # formed in LDS and never stored (nvq_pw_bn_backward)
             K.pw_bn_backward(dcur, sv.pws[k], sv.dws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
                              P[pre + "bn.bias"], sv.training, P[pre + "pointwise.weight"], dd, G[pre + "bn.weight"],
-                             G[pre + "bn.bias"], G[pre + "pointwise.weight"], ws)
+                             G[pre + "bn.bias"], G[pre + "pointwise.weight"], ws, sums_in=bn_sums)
+            bn_sums = None
         else:
             dp = _new(dev, NI, H, W, F, dtype=act_dtype)
             K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
@@ -472,7 +477,15 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             # first layer: with the skip-path add and the head's ReLU mask in its epilogue the one-tile kernel takes as long as
             # the two launches below (2.53 vs 2.54 ms: the epilogue operands are loaded where they are used, by 8 waves per CU)
             dx = _new(dev, NI, H, W, F, dtype=act_dtype)
-            K.dwconv_backward(xin, xin_bn, dd, P[pre + "depthwise.weight"], dx, G[pre + "depthwise.weight"], ws)
+            prev = f"feature_extractor.body.{k - 1}."
+            if fuse_sums and sv.training and os.environ.get("NVQ_FUSED_PW_BWD", "1") != "0":
+                # ... and the backward sums of layer k - 1's BatchNorm: this kernel holds its input (xin) and the gradient of
+                # its activation (dx), so the next pw_bn_backward needs no reduce pass of its own
+                bn_sums = _new(dev, T, 2, F)
+                K.dwconv_backward(xin, xin_bn, dd, P[pre + "depthwise.weight"], dx, G[pre + "depthwise.weight"], ws,
+                                  bn_sums=bn_sums, bn_dgamma=G[prev + "bn.weight"], bn_dbeta=G[prev + "bn.bias"])
+            else:
+                K.dwconv_backward(xin, xin_bn, dd, P[pre + "depthwise.weight"], dx, G[pre + "depthwise.weight"], ws)
             dcur = dx
             continue
         K.dwconv_wgrad(xin, dd, G[pre + "depthwise.weight"], ws, bn=xin_bn)

@@ -91,9 +91,9 @@ SIGNATURES = {
     "nvq_bn_eval_stats": (ci, [vp, vp, ci, ci, cf, vp, vp, vp]),
     "nvq_bn_apply_relu": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
     "nvq_bn_relu_backward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, sz, ci, ci, ci, ci, vp]),
-    "nvq_dwconv_backward": (ci, [vp, ci, vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp, vp, sz, vp]),
+    "nvq_dwconv_backward": (ci, [vp, ci, vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_dwpw_forward": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
-    "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, sz, vp]),
+    "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
@@ -626,10 +626,12 @@ def bn_relu_backward(dy: torch.Tensor, x: torch.Tensor, group_images: int, mean,
 
 
 def dwconv_backward(x: torch.Tensor, bn, dy: torch.Tensor, weight: torch.Tensor, dx: torch.Tensor, dweight, ws,
-                    add: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> None:
+                    add: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, bn_sums=None, bn_dgamma=None,
+                    bn_dbeta=None) -> None:
     """Input and weight gradient of a 64-channel depthwise 3x3 conv from one staged tile (bf16 mode): see nvq_dwconv_backward.
     bn = (mean, invstd, gamma, beta, group_images): the conv was fed relu(bn(x)); add (fp32) / mask (bf16): dx = (dx + add)
-    where mask > 0."""
+    where mask > 0.  bn_sums [G, 2, 64] (+ bn_dgamma, bn_dbeta [64]): also return the backward sums of that BatchNorm (its input is
+    x, the gradient of its activation is dx) - pw_bn_backward(..., sums_in=bn_sums) then skips its reduce pass."""
     N, H, W, ld = x.shape
     assert x.dtype == dy.dtype == dx.dtype == torch.bfloat16 and weight.shape[0] == 64
     b = _bn_input(bn)
@@ -640,7 +642,8 @@ def dwconv_backward(x: torch.Tensor, bn, dy: torch.Tensor, weight: torch.Tensor,
         e.mask, e.mask_ld, e.mask_bf16 = ptr(mask), mask.shape[-1] if mask is not None else 0, is_bf16(mask)
     check(lib().nvq_dwconv_backward(ptr(x), ld, C.byref(b) if b is not None else None, ptr(dy), dy.shape[-1],
                                     ptr(weight.contiguous()), ptr(dx), dx.shape[-1], C.byref(e) if e is not None else None,
-                                    N, H, W, ptr(dweight), ptr(ws), ws.numel() * 4, stream()), "nvq_dwconv_backward")
+                                    N, H, W, ptr(dweight), ptr(bn_sums), ptr(bn_dgamma), ptr(bn_dbeta), ptr(ws), ws.numel() * 4,
+                                    stream()), "nvq_dwconv_backward")
 
 
 def dwpw_forward(x: torch.Tensor, bn, dw_weight: torch.Tensor, pw_weight: torch.Tensor, d: torch.Tensor, p: torch.Tensor,
@@ -664,7 +667,7 @@ def dwpw_forward(x: torch.Tensor, bn, dw_weight: torch.Tensor, pw_weight: torch.
 
 
 def pw_bn_backward(dy: torch.Tensor, p: torch.Tensor, d: torch.Tensor, group_images: int, mean, invstd, gamma, beta,
-                   training: bool, weight: torch.Tensor, dd: torch.Tensor, dgamma, dbeta, dweight, ws) -> None:
+                   training: bool, weight: torch.Tensor, dd: torch.Tensor, dgamma, dbeta, dweight, ws, sums_in=None) -> None:
     """Backward of pointwise conv -> BatchNorm -> ReLU in one pass (bf16 mode, 64 channels): see nvq_pw_bn_backward."""
     N, H, W, _ = p.shape
     assert p.dtype == d.dtype == dd.dtype == torch.bfloat16 and tuple(weight.shape[:2]) == (64, 64)
@@ -672,7 +675,7 @@ def pw_bn_backward(dy: torch.Tensor, p: torch.Tensor, d: torch.Tensor, group_ima
     check(lib().nvq_pw_bn_backward(ptr(dy), dy.shape[-1], is_bf16(dy), ptr(p), p.shape[-1], ptr(d), d.shape[-1], N,
                                    group_images, H, W, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(training),
                                    ptr(weight.contiguous()), ptr(dd), dd.shape[-1], ptr(dgamma), ptr(dbeta), ptr(dweight),
-                                   ptr(ws), ws.numel() * 4, stream()), "nvq_pw_bn_backward")
+                                   ptr(sums_in), ptr(ws), ws.numel() * 4, stream()), "nvq_pw_bn_backward")
     if ev0 is not None:
         npx = N * H * W
         TIMER.stop(ev0, "pw_bn_bwd_kernel", 2.0 * npx * 64 * 64 * 2,

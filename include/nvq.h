@@ -160,11 +160,14 @@ size_t nvq_sizeof_wgrad_desc(void);
  * and never stored).  dy [N,H,W,dy_ld]: gradient w.r.t. relu(bn(p)), fp32 or bf16; p: the conv output = BatchNorm input, d: the
  * conv input (both bf16); groups of `group_images` images have their own statistics mean / invstd [G][64];
  * weight [64 co][64 ci] fp32.  Outputs: dd (bf16) = gradient w.r.t. d; dgamma, dbeta [64]; dweight [64][64] (all overwritten).
+ * sums_in != NULL: the BatchNorm sums [G][2][64] already computed (nvq_dwconv_backward's bn_sums for the same dy and p):
+ * the reduce pass is skipped and dgamma / dbeta are left alone (that call wrote them).
  * workspace: nvq_wgrad_workspace_bytes() is enough. */
 int nvq_pw_bn_backward(const float* dy, int dy_ld, int dy_bf16, const float* p, int p_ld, const float* d, int d_ld,
                        int N, int group_images, int H, int W, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int training, const float* weight, float* dd, int dd_ld,
-                       float* dgamma, float* dbeta, float* dweight, float* workspace, size_t workspace_bytes, void* stream);
+                       float* dgamma, float* dbeta, float* dweight, const float* sums_in, float* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ feature extractor
  * FeatureExtractor.head, super_resolution.py:40-43: relu(conv3x3(frame; W[F,Cin,3,3], b)).
@@ -217,10 +220,15 @@ int nvq_dwconv_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, int C
  * x [N,H,W,x_ld] bf16: the conv's input; bn != NULL: the input was relu(bn(x)) (evaluated while x is staged, as in
  * nvq_dwconv_wgrad); dy: gradient w.r.t. the conv output, bf16; weight [64][3][3] fp32.  Outputs: dx (bf16, overwritten) =
  * gradient w.r.t. the conv input, through the optional epilogue dx = (dx + add) where mask > 0 (add fp32, mask bf16);
- * dweight [64][3][3] (overwritten).  workspace >= 512*576 floats. */
+ * dweight [64][3][3] (overwritten).  bn_sums != NULL (needs bn, no epi): the kernel holds both operands of the BACKWARD of that
+ * BatchNorm + ReLU - its input x and the gradient dx of its output - and also returns the per-group sums bn_sums [G][2][64]
+ * = {sum g, sum g xhat} (g = dx where relu(bn(x)) > 0) and bn_dgamma / bn_dbeta [64] (overwritten): what the first half of
+ * nvq_bn_relu_backward / nvq_pw_bn_backward computes in a pass of its own; hand bn_sums to nvq_pw_bn_backward(sums_in).
+ * workspace >= 512*(576+128) floats. */
 int nvq_dwconv_backward(const float* x, int x_ld, const nvq_bn_input* bn, const float* dy, int dy_ld, const float* weight,
                         float* dx, int dx_ld, const nvq_dw_epilogue* epi, int N, int H, int W, float* dweight,
-                        float* workspace, size_t workspace_bytes, void* stream);
+                        float* bn_sums, float* bn_dgamma, float* bn_dbeta, float* workspace, size_t workspace_bytes,
+                        void* stream);
 /* Forward of  depthwise 3x3 -> pointwise 1x1 (no bias) -> BatchNorm2d statistics  of a DepthwiseSeparableConv
  * (efficient_layers.py:49-66) in the bf16 mode, 64 channels: what nvq_dwconv_forward + nvq_conv_forward (1x1) + nvq_bn_stats
  * do in three launches (five tensor passes), in one pass x -> d, p.  in [N,H,W,in_ld] bf16; bn != NULL: x := relu(bn(x)) is

@@ -859,6 +859,30 @@ def test_depthwise_backward_input_and_weight_gradient_from_one_tile(K, with_bn, 
         want = (want + from_nhwc(add)) * (mask_c > 0)
     assert rel(from_nhwc(dx.float()), want) < 5e-3             # one bf16 rounding of the result
     assert rel(dw, wg.grad) < TOL
+    if with_bn and not with_epi:
+        # the same call also returning the backward sums of the input's BatchNorm (x = its input, dx = the gradient of its
+        # activation): equal to what the BatchNorm backward computes from (dx, x) in a pass of its own, and usable by
+        # nvq_pw_bn_backward in place of that pass
+        sums = torch.zeros(G, 2, C, device="cuda")
+        dga, dbe = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dx_s, dw_s = torch.zeros_like(dx), torch.zeros_like(dw)
+        K.dwconv_backward(xb, bn, dyb, wd.cuda(), dx_s, dw_s, ws, bn_sums=sums, bn_dgamma=dga, bn_dbeta=dbe)
+        assert torch.equal(dx_s, dx) and rel(dw_s, dw) < 2e-5
+        dp_ref = torch.empty_like(dx)
+        dga_ref, dbe_ref = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        K.bn_relu_backward(dx, xb, B, m0, i0, gamma, beta, True, dp_ref, dga_ref, dbe_ref, ws)
+        assert rel(dga, dga_ref) < 2e-5 and rel(dbe, dbe_ref) < 2e-5
+        # through the pointwise backward: the hand-off gives the same dd / dweight as its own reduce pass
+        wpw = bf(rnd(C, C, 1, 1, scale=0.15, seed=9)).cuda()
+        dprev = to_nhwc_bf16(bf(rnd(N, C, H, W, seed=10)))
+        outs = []
+        for s_in in (None, sums):
+            dd = torch.zeros_like(dx)
+            g1, g2, gw = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, C, 1, 1, device="cuda")
+            K.pw_bn_backward(dx, xb, dprev, B, m0, i0, gamma, beta, True, wpw, dd, g1, g2, gw, ws, sums_in=s_in)
+            outs.append((dd, gw, g1))
+        assert rel(outs[1][0].float(), outs[0][0].float()) < 1e-2 and rel(outs[1][1], outs[0][1]) < 1e-4
+        assert rel(outs[0][2], dga_ref) < 2e-5 and not outs[1][2].any()      # with sums_in, dgamma / dbeta are left alone
 
 
 @pytest.mark.parametrize("C,N,H,W", [(64, 2, 11, 37), (128, 1, 8, 32), (64, 3, 17, 70)])
