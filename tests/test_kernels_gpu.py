@@ -943,6 +943,27 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
     assert rel(dx2m, dx2) < 1e-6                              # same products, same order per pixel
 
 
+@pytest.mark.parametrize("C,B,R,H,W", [(64, 1, 2, 70, 20), (32, 2, 1, 45, 37), (64, 1, 1, 8, 16), (64, 1, 1, 131, 9)])
+@pytest.mark.parametrize("store_bf16", [False, True])
+def test_correlation_forward_strip_kernel(K, C, B, R, H, W, store_bf16):
+    """bf16-stored features take the strip form of the forward (a workgroup walks down a column block with the halo rows as a
+    ring in LDS): segments of several tiles (H = 70, 131: the ring rotates more than once), of one tile, and empty ones (H = 8);
+    against the tile form on the same values stored as fp32 (same operands, same MFMA order: equal) and the oracle."""
+    N = B * R
+    x1 = bf(rnd(N, C, H, W))
+    x2 = bf(rnd(B, C, H, W, seed=3))
+    want = torch.cat([sr_oracle.correlation(x1[r * B:(r + 1) * B], x2) for r in range(R)], 0)
+    ld = 96
+    odt = torch.bfloat16 if store_bf16 else torch.float32
+    got = torch.full((N, H, W, ld), 3.0, device="cuda", dtype=odt)
+    K.correlation_forward(K.Sl(to_nhwc_bf16(x1)), K.Sl(to_nhwc_bf16(x2, 3 * C, C), C, C), got, math=K.MATH_BF16)
+    tile = torch.full((N, H, W, ld), 3.0, device="cuda", dtype=odt)
+    K.correlation_forward(K.Sl(to_nhwc(x1)), K.Sl(to_nhwc(x2, 3 * C, C), C, C), tile, math=K.MATH_BF16)
+    assert torch.equal(got, tile)
+    assert rel(from_nhwc(got.float(), 81), want) < (5e-3 if store_bf16 else TOL)
+    assert got[..., 81:].float().abs().max().item() == 0
+
+
 @pytest.mark.parametrize("Fc,N,H,W", [(64, 2, 19, 37), (64, 1, 16, 32), (32, 2, 9, 20)])
 def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
     """nvq_conv_desc::in_plane / nvq_wgrad_desc::x_plane: the dense-block buffer as compact tensors [x | y_0 | ..] in one
