@@ -153,8 +153,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = CS == 1 ? tid >> 6 : (tid >> 6) & (NW / CS - 1);   // the wave's row pair in the tile
-    const int half = CS == 1 ? 0 : tid >> 8;                  // ... and its half of the workgroup's output channels
+    // (wave-uniform, so kept in scalar registers: as vector values the channel-split variant spilled them around its main loop)
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = CS == 1 ? wid : wid & (NW / CS - 1);     // the wave's row pair in the tile
+    const int half = CS == 1 ? 0 : wid >> 2;                  // ... and its half of the workgroup's output channels
     const int c = lane & 15;
     const int g = lane >> 4;
 
