@@ -345,7 +345,8 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
                                                             const float* __restrict__ other, int other_ld,
                                                             int other_images, int H, int W, int tilesX, int tilesY,
                                                             float* __restrict__ dx, int dx_ld, int dx_coff,
-                                                            int accumulate, int other_bf16, int groups, int group_images) {
+                                                            int accumulate, int other_bf16, int groups, int group_images,
+                                                            __bf16* __restrict__ dx16, int dx16_ld) {
     constexpr int YS = WHICH == 1 ? C + 8 : C + 16;
     constexpr int NCB = C / 16;
     constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
@@ -468,7 +469,11 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
     for (int cb = 0; cb < NCB; ++cb) {
         float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
         if (accumulate) { v.x += old[cb].x; v.y += old[cb].y; v.z += old[cb].z; v.w += old[cb].w; }
-        st4(op + cb * 16, v);
+        if (dx16)   // the last pass over an accumulated gradient: the sum leaves as bf16 (dx is only read)
+            *reinterpret_cast<bf16x4*>(dx16 + ((size_t)(n0 * H + gy) * W + gx) * dx16_ld + cb * 16 + 4 * g) =
+                (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        else
+            st4(op + cb * 16, v);
     }
 }
 
@@ -502,14 +507,14 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
 
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       int other_bf16, int groups, hipStream_t s) {
+                       int other_bf16, int groups, float* dx16, int dx16_ld, hipStream_t s) {
     NVQ_REQUIRE(!other_bf16 || other_ld % 8 == 0, "correlation_backward(bf16): a bf16 `other` needs ld %% 8 == 0");
     NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
                 "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \
-    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N)
+    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N, reinterpret_cast<__bf16*>(dx16), dx16_ld)
 #define NVQ_CB2(CC) \
     do { if (which == 1) { if (dcorr_bf16) NVQ_CB(CC, 1, true); else NVQ_CB(CC, 1, false); } \
          else { if (dcorr_bf16) NVQ_CB(CC, 2, true); else NVQ_CB(CC, 2, false); } } while (0)

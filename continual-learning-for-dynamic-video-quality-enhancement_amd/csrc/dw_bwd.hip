@@ -318,7 +318,7 @@ extern "C" int nvq_dwconv_backward(const float* x, int x_ld, const nvq_bn_input*
     NVQ_REQUIRE(x_ld % 8 == 0 && dy_ld % 8 == 0 && dx_ld % 8 == 0 && x_ld >= FC && dy_ld >= FC && dx_ld >= FC && aligned16(x) &&
                     aligned16(dy) && aligned16(dx),
                 "dwconv_backward: 64-channel bf16 tensors, 16-byte addressable");
-    NVQ_REQUIRE(!epi || ((!epi->add || (epi->add_ld % 4 == 0 && aligned16(epi->add))) &&
+    NVQ_REQUIRE(!epi || ((!epi->add || (epi->add_ld % 4 == 0 && aligned16(epi->add) && !epi->add_bf16)) &&
                          (!epi->mask || (epi->mask_bf16 && epi->mask_ld % 4 == 0))),
                 "dwconv_backward: epilogue takes an fp32 addend and a bf16 mask");
     NVQ_REQUIRE((long)N * H * W < ((long)1 << 31), "dwconv_backward: too many pixels");

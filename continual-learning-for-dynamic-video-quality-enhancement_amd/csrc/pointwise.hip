@@ -559,7 +559,7 @@ __device__ __forceinline__ float4 dw_unpack4(dw_u32x2 v) {
 // staged instead of in a pass of its own (same expression and the same single bf16 rounding as bn_apply_relu_kernel, so the
 // staged values are the ones that kernel would have stored).  Zero padding stays zero.
 // Optional epilogue of dwconv_bf16_kernel: out = (conv + add) masked by (mask > 0); add is fp32, mask bf16 or fp32.
-struct DwEpi { const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16; };
+struct DwEpi { const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16; int add_bf16; };
 struct DwBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int group_images; int C; };
 
 __device__ __forceinline__ void dw_stage_halo_bf16(const __bf16* __restrict__ in, int in_ld, int n, int H, int W, int ty0,
@@ -621,7 +621,9 @@ __device__ __forceinline__ float4 dw_lds4(const __bf16* xs, int hp, int c4) {
 constexpr int DB_MAXWG = 512;
 // HAS_BN / HAS_EPI: the optional input transform / output epilogue as template parameters - as run-time branches their
 // registers (32 for the BatchNorm parameters) counted against the 128-register budget of every launch.
-template <bool HAS_BN, bool HAS_EPI>
+// EPI: 0 no epilogue, 1 the general one (storage types as run-time flags), 2 add and mask both present and both bf16 - their
+// two 8-byte loads are then issued together (behind a run-time flag each is a branch that waits for its own load).
+template <bool HAS_BN, int EPI>
 __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
@@ -722,11 +724,21 @@ __global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __re
                 const int gy = ty * DT_H + y;
                 if (gy < H && gx < W) {
                     const size_t pix = (size_t)(n * H + gy) * W + gx;
-                    if (HAS_EPI && ep.add) {
-                        const float4 a = ld4(ep.add + pix * ep.add_ld + ch0 + 4 * c4);
+                    if constexpr (EPI == 2) {
+                        const dw_u32x2 ra = *reinterpret_cast<const dw_u32x2*>(reinterpret_cast<const __bf16*>(ep.add) + pix * ep.add_ld + ch0 + 4 * c4);
+                        const dw_u32x2 rm = *reinterpret_cast<const dw_u32x2*>(reinterpret_cast<const __bf16*>(ep.mask) + pix * ep.mask_ld + ch0 + 4 * c4);
+                        const float4 a = dw_unpack4(ra), m = dw_unpack4(rm);
+                        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                        if (!(m.x > 0.f)) acc.x = 0.f;
+                        if (!(m.y > 0.f)) acc.y = 0.f;
+                        if (!(m.z > 0.f)) acc.z = 0.f;
+                        if (!(m.w > 0.f)) acc.w = 0.f;
+                    }
+                    if (EPI == 1 && ep.add) {
+                        const float4 a = ldx4(ep.add, pix * ep.add_ld + ch0 + 4 * c4, ep.add_bf16);
                         acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
                     }
-                    if (HAS_EPI && ep.mask) {
+                    if (EPI == 1 && ep.mask) {
                         const float4 m = ldx4(ep.mask, pix * ep.mask_ld + ch0 + 4 * c4, ep.mask_bf16);
                         if (!(m.x > 0.f)) acc.x = 0.f;
                         if (!(m.y > 0.f)) acc.y = 0.f;
@@ -1229,8 +1241,8 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
     NVQ_REQUIRE(!epi || (C % DB_C == 0 && in_bf16 && (!epi->add || epi->add_ld % 4 == 0) &&
                          (!epi->mask || epi->mask_ld % 4 == 0)),
                 "dwconv_forward: the add / mask epilogue needs a bf16 input with C %% 64 == 0");
-    DwEpi ep = {nullptr, 0, nullptr, 0, 0};
-    if (epi) { ep.add = epi->add; ep.add_ld = epi->add_ld; ep.mask = epi->mask; ep.mask_ld = epi->mask_ld; ep.mask_bf16 = epi->mask_bf16; }
+    DwEpi ep = {nullptr, 0, nullptr, 0, 0, 0};
+    if (epi) { ep.add = epi->add; ep.add_ld = epi->add_ld; ep.mask = epi->mask; ep.mask_ld = epi->mask_ld; ep.mask_bf16 = epi->mask_bf16; ep.add_bf16 = epi->add_bf16; }
     NVQ_REQUIRE(!bn || (C % DB_C == 0 && in_bf16 && bn->group_images > 0 && N % bn->group_images == 0),
                 "dwconv_forward: the fused BatchNorm input needs a bf16 tensor with C %% 64 == 0");
     NVQ_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0 && aligned16(in) && aligned16(out),
@@ -1245,10 +1257,15 @@ int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C, f
     hipLaunchKernelGGL((dwconv_bf16_kernel<B_, E_>), dim3(nwg, C / DB_C), dim3(DB_T), 0, (hipStream_t)stream,               \
                        reinterpret_cast<const __bf16*>(in), in_ld, weight, C, out, out_ld, H, W, tilesX, tilesY, ntiles, flip, \
                        out_bf16, make_dwbn(bn, C), ep)
-        if (bn && epi) NVQ_DWB(true, true);
-        else if (bn) NVQ_DWB(true, false);
-        else if (epi) NVQ_DWB(false, true);
-        else NVQ_DWB(false, false);
+        const bool epb = epi && epi->add && epi->mask && epi->add_bf16 && epi->mask_bf16 && epi->add_ld % 4 == 0 &&
+                         epi->mask_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(epi->add) & 7) == 0 &&
+                         (reinterpret_cast<uintptr_t>(epi->mask) & 7) == 0;
+        if (bn && epb) NVQ_DWB(true, 2);
+        else if (bn && epi) NVQ_DWB(true, 1);
+        else if (bn) NVQ_DWB(true, 0);
+        else if (epb) NVQ_DWB(false, 2);
+        else if (epi) NVQ_DWB(false, 1);
+        else NVQ_DWB(false, 0);
 #undef NVQ_DWB
         return check_launch("dwconv_bf16");
     }

@@ -442,12 +442,22 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         _capture("dflow", dflow)
         _capture("dcorr", dcorr)
         center = Sl(sv.aligned, F, c * F)
-        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math)
+        # The two correlation gradients are the LAST terms of the feature gradient.  bf16 activation mode: they write the finished
+        # sum as bf16 (dfeat16) instead of back into the fp32 accumulator - the extractor's backward reads it three times
+        # (BatchNorm sums, pointwise backward, the skip add of the first depthwise layer) at half the bytes, like every other
+        # gradient it consumes.
+        feat16 = (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F in (32, 64) and sv.img8 is not None
+                  and os.environ.get("NVQ_BF16_FEATURE_GRAD", "1") != "0")
+        dfeat16 = _new(dev, NI, H, W, F, dtype=torch.bfloat16) if feat16 else None
+        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math, out16=dfeat16[B:] if feat16 else None)
         # gradient w.r.t. the centre frame's features: the T - 1 reference frames in one pass (one read-modify-write)
-        K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), True, math=math, groups=T - 1)
+        K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), True, math=math, groups=T - 1,
+                               out16=dfeat16[:B] if feat16 else None)
+        if feat16:
+            dfeat_all = dfeat16
 
     # ---- feature extractor (all frames batched)
-    _capture("dfeat_all", dfeat_all)
+    _capture("dfeat_all", lambda: dfeat_all.float())
     dcur = dfeat_all
     bn_sums = None                    # BatchNorm-backward sums of layer k, when the depthwise backward of layer k + 1 left them
     # (built and measured, off by default: with the sums in it the depthwise backward only fits its registers with two instead

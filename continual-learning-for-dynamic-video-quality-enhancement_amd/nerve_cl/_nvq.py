@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
 
 
 class DwEpilogue(C.Structure):
-    _fields_ = [("add", vp), ("add_ld", ci), ("mask", vp), ("mask_ld", ci), ("mask_bf16", ci)]
+    _fields_ = [("add", vp), ("add_ld", ci), ("mask", vp), ("mask_ld", ci), ("mask_bf16", ci), ("add_bf16", ci)]
 
 
 class BnInput(C.Structure):
@@ -95,7 +95,7 @@ SIGNATURES = {
     "nvq_dwpw_forward": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
@@ -571,7 +571,7 @@ def dwconv_forward(x: torch.Tensor, weight, out: torch.Tensor, flip=False, bn=No
     e = None
     if add is not None or mask is not None:
         e = DwEpilogue()
-        e.add, e.add_ld = ptr(add), add.shape[-1] if add is not None else 0
+        e.add, e.add_ld, e.add_bf16 = ptr(add), add.shape[-1] if add is not None else 0, is_bf16(add)
         e.mask, e.mask_ld, e.mask_bf16 = ptr(mask), mask.shape[-1] if mask is not None else 0, is_bf16(mask)
     check(lib().nvq_dwconv_forward(ptr(x), ld, ptr(weight), Cc, ptr(out), out.shape[-1], N, H, W, int(flip),
                                    is_bf16(x), is_bf16(out), C.byref(b) if b is not None else None,
@@ -638,7 +638,7 @@ def dwconv_backward(x: torch.Tensor, bn, dy: torch.Tensor, weight: torch.Tensor,
     e = None
     if add is not None or mask is not None:
         e = DwEpilogue()
-        e.add, e.add_ld = ptr(add), add.shape[-1] if add is not None else 0
+        e.add, e.add_ld, e.add_bf16 = ptr(add), add.shape[-1] if add is not None else 0, is_bf16(add)
         e.mask, e.mask_ld, e.mask_bf16 = ptr(mask), mask.shape[-1] if mask is not None else 0, is_bf16(mask)
     check(lib().nvq_dwconv_backward(ptr(x), ld, C.byref(b) if b is not None else None, ptr(dy), dy.shape[-1],
                                     ptr(weight.contiguous()), ptr(dx), dx.shape[-1], C.byref(e) if e is not None else None,
@@ -692,14 +692,14 @@ def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor, math: int = MATH_F32)
 
 
 def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32,
-                         groups: int = 1):
+                         groups: int = 1, out16: Optional[torch.Tensor] = None):
     """groups > 1 (which == 2): dcorr / other hold groups * N images, frame-major; dx (N images) collects all of them in
-    one pass"""
+    one pass.  out16 (bf16 [N/groups, H, W, >= C]): the finished gradient is written there as bf16 instead of back to dx."""
     N, H, W, ld = dcorr.shape
-    assert N % groups == 0
+    assert N % groups == 0 and (out16 is None or out16.dtype == torch.bfloat16)
     check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N // groups, H, W,
                                          ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), other.bf16,
-                                         groups, stream()),
+                                         groups, ptr(out16), out16.shape[-1] if out16 is not None else 0, stream()),
           "nvq_correlation_backward")
 
 

@@ -201,11 +201,11 @@ typedef struct nvq_bn_input {
     const float* mean; const float* invstd; const float* gamma; const float* beta;
     int group_images;
 } nvq_bn_input;
-/* epi != NULL (same kernels): out = (conv + add) where mask > 0, else 0.  add: fp32 [.., add_ld] or NULL; mask: fp32 or
- * bf16 [.., mask_ld] or NULL.  Used for the last depthwise input gradient of the feature extractor, which so leaves the
+/* epi != NULL (same kernels): out = (conv + add) where mask > 0, else 0.  add: fp32 or bf16 (add_bf16) [.., add_ld] or NULL;
+ * mask: fp32 or bf16 [.., mask_ld] or NULL.  Used for the last depthwise input gradient of the feature extractor, which so leaves the
  * kernel as the ReLU-masked gradient of the head conv (skip path added). */
 typedef struct nvq_dw_epilogue {
-    const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16;
+    const float* add; int add_ld; const float* mask; int mask_ld; int mask_bf16; int add_bf16;
 } nvq_dw_epilogue;
 int nvq_dwconv_forward(const float* in, int in_ld, const float* weight, int C,
                        float* out, int out_ld, int N, int H, int W, int flip,
@@ -295,11 +295,15 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
  *             groups > 1: dcorr and other hold groups * N images (frame-major: the T - 1 reference frames of every clip);
  *             dx[n] collects from images n, n + N, ... in that order in ONE pass (one read-modify-write of the shared
  *             centre-frame gradient instead of one per frame)
- * math / dcorr_bf16 / other_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96).  dx is fp32. */
+ * math / dcorr_bf16 / other_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96).  dx is fp32.
+ * dx_bf16_out != NULL (matrix-core path): this is the LAST pass over an accumulated gradient - the result (dx + the new
+ * term when accumulate) is written as bf16 to dx_bf16_out [N,H,W,dx_bf16_ld] channels [0,C) instead of back to dx, which
+ * is only read: the readers of the finished gradient then move half the bytes. */
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
                              const float* other, int other_ld, int other_images, int C, int N,
                              int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                             int math, int dcorr_bf16, int other_bf16, int groups, void* stream);
+                             int math, int dcorr_bf16, int other_bf16, int groups, float* dx_bf16_out, int dx_bf16_ld,
+                             void* stream);
 
 /* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
  * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2] fp32.

@@ -941,6 +941,18 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
     K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(dx2m), False, math=K.MATH_BF16, groups=R)
     assert rel(from_nhwc(dx2m), x2.grad) < TOL
     assert rel(dx2m, dx2) < 1e-6                              # same products, same order per pixel
+    # the last pass over an accumulated gradient can leave as bf16 instead (dx is then only read)
+    acc0 = to_nhwc(rnd(N, C, H, W, seed=7))
+    keep = acc0.clone()
+    o16 = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.correlation_backward(1, dcorr, K.Sl(al, C, C), K.Sl(acc0), True, math=K.MATH_BF16, out16=o16)
+    assert torch.equal(o16, dx1.bfloat16()) and torch.equal(acc0, keep)
+    acc2 = to_nhwc(rnd(B, C, H, W, seed=8))
+    want2 = acc2.clone()
+    K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(want2), True, math=K.MATH_BF16, groups=R)
+    o2 = torch.zeros(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(acc2), True, math=K.MATH_BF16, groups=R, out16=o2)
+    assert torch.equal(o2, want2.bfloat16())
 
 
 @pytest.mark.parametrize("C,B,R,H,W", [(64, 1, 2, 70, 20), (32, 2, 1, 45, 37), (64, 1, 1, 8, 16), (64, 1, 1, 131, 9)])
