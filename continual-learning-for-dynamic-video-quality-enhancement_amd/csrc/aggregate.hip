@@ -29,7 +29,7 @@ static inline int tsum_blocks_host(int H, int W) {
 
 // ---------------------------------------------------------------- softmax-weighted sum
 // grid (nblk, N)
-template <int TMAX, int TU, bool AB>
+template <int TMAX, int TU, bool AB, bool WB>                 // WB: `weighted` is stored as bf16 (the GAP sums use the unrounded values)
 __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__ aligned, int aligned_ld,
                                                        const float* __restrict__ logits, int logits_ld, int T,
                                                        int C, long HW, float* __restrict__ attn, int attn_ld,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__
             }
             if (c4 == 0)
                 for (int t = T; t < attn_ld; ++t) attn[pix * attn_ld + t] = 0.f;
-            st4(weighted + pix * weighted_ld + 4 * c4, o);
+            stx4(weighted, pix * weighted_ld + 4 * c4, WB, o);
             gsum.x += o.x; gsum.y += o.y; gsum.z += o.z; gsum.w += o.w;
         }
     }
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void tsum_fwd_kernel(const float* __restrict__
         st4(gap_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + 4 * c4, r);
 }
 
-template <bool ALLB>                                          // ALLB: aligned and daligned are bf16, known at compile time
+template <bool ALLB, bool WB>                                 // ALLB: aligned and daligned are bf16, known at compile time; WB: dweighted too
 __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__ dweighted, int dweighted_ld,
                                                        const float* __restrict__ dgap_pix,
                                                        const float* __restrict__ aligned, int aligned_ld,
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void tsum_bwd_kernel(const float* __restrict__
     const long pix = idiv(gid, C4, total);
     const int c4 = (int)(gid - pix * C4);
     const int n = (int)idiv(pix, HW, total);
-    float4 dw = ld4(dweighted + pix * dweighted_ld + 4 * c4);
+    float4 dw = ldx4(dweighted, pix * dweighted_ld + 4 * c4, WB);
     if (dgap_pix) {
         const float4 gp = ld4(dgap_pix + (size_t)n * C + 4 * c4);
         dw.x += gp.x; dw.y += gp.y; dw.z += gp.z; dw.w += gp.w;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void cbam_channel_kernel(const float* __restri
     }
 }
 
+template <bool XB>                                            // XB: x is stored as bf16
 __global__ __launch_bounds__(256) void cbam_pool_kernel(const float* __restrict__ x, int x_ld,
                                                         const float* __restrict__ ca, int C, long HW,
                                                         float* __restrict__ sm, int* __restrict__ amax, long total) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void cbam_pool_kernel(const float* __restrict_
     const long pix = idiv(gid, C4, total);
     const int c4 = (int)(gid - pix * C4);
     const int n = (int)idiv(pix, HW, total);
-    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 v = ldx4(x, pix * x_ld + 4 * c4, XB);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float e[4] = {v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w};
     const float s = group_sum(e[0] + e[1] + e[2] + e[3], C4);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void cbam_sa_kernel(const float* __restrict__ 
     sa[(size_t)(n * H + gy) * W + gx] = sigmoidf_(s);
 }
 
+template <bool XB>
 __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ x, int x_ld,
                                                          const float* __restrict__ ca, const float* __restrict__ sa,
                                                          int C, long HW, float* __restrict__ out, int out_ld,
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
     const long pix = idiv(gid, C4, total);
     const int c4 = (int)(gid - pix * C4);
     const int n = (int)idiv(pix, HW, total);
-    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 v = ldx4(x, pix * x_ld + 4 * c4, XB);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float s = sa[pix];
     const float4 o = make_float4(v.x * a.x * s, v.y * a.y * s, v.z * a.z * s, v.w * a.w * s);
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- CBAM backward
+template <bool XB>                                            // XB: dout and x are stored as bf16
 __global__ __launch_bounds__(256) void cbam_bwd_pre_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                            const float* __restrict__ x, int x_ld,
                                                            const float* __restrict__ ca, const float* __restrict__ sa,
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_pre_kernel(const float* __restri
     const long pix = idiv(gid, C4, total);
     const int c4 = (int)(gid - pix * C4);
     const int n = (int)idiv(pix, HW, total);
-    const float4 g = ld4(dout + pix * dout_ld + dout_coff + 4 * c4);
-    const float4 v = ld4(x + pix * x_ld + 4 * c4);
+    const float4 g = ldx4(dout, pix * dout_ld + dout_coff + 4 * c4, XB);
+    const float4 v = ldx4(x, pix * x_ld + 4 * c4, XB);
     const float4 a = ld4(ca + (size_t)n * C + 4 * c4);
     const float d = group_sum(g.x * v.x * a.x + g.y * v.y * a.y + g.z * v.z * a.z + g.w * v.w * a.w, C4);
     if (c4 == 0) {
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_conv_kernel(const float* __restr
     }
 }
 
-// grid (nblk, N)
+// grid (nblk, N).  XB: dout, x and dx are stored as bf16
+template <bool XB>
 __global__ __launch_bounds__(256) void cbam_bwd_scale_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                              const float* __restrict__ x, int x_ld,
                                                              const float* __restrict__ ca, const float* __restrict__ sa,
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_scale_kernel(const float* __rest
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long p = (long)blockIdx.x * npl + pl; p < HW; p += (long)gridDim.x * npl) {
         const long pix = base + p;
-        const float4 g = ld4(dout + pix * dout_ld + dout_coff + 4 * c4);
-        const float4 v = ld4(x + pix * x_ld + 4 * c4);
+        const float4 g = ldx4(dout, pix * dout_ld + dout_coff + 4 * c4, XB);
+        const float4 v = ldx4(x, pix * x_ld + 4 * c4, XB);
         const float s = sa[pix];
         const float d0 = dsm[pix * 2] * invC, d1 = dsm[pix * 2 + 1];
         const int am = amax[pix] - 4 * c4;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) void cbam_bwd_scale_kernel(const float* __rest
         dxc.y = g.y * s + d0 + (am == 1 ? d1 : 0.f);
         dxc.z = g.z * s + d0 + (am == 2 ? d1 : 0.f);
         dxc.w = g.w * s + d0 + (am == 3 ? d1 : 0.f);
-        st4(dx + pix * dx_ld + 4 * c4, make_float4(dxc.x * a.x, dxc.y * a.y, dxc.z * a.z, dxc.w * a.w));
+        stx4(dx, pix * dx_ld + 4 * c4, XB, make_float4(dxc.x * a.x, dxc.y * a.y, dxc.z * a.z, dxc.w * a.w));
         acc.x += dxc.x * v.x; acc.y += dxc.y * v.y; acc.z += dxc.z * v.z; acc.w += dxc.w * v.w;
     }
     const float4 r = plane_reduce4b(acc, buf, C4, npl);
@@ -451,15 +455,18 @@ int nvq_tsum_blocks(int H, int W) { return tsum_blocks_host(H, W); }
 
 int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, int logits_ld, int T, int C,
                      int N, int H, int W, float* attn, int attn_ld, float* weighted, int weighted_ld,
-                     float* gap_partial, int aligned_bf16, void* stream) {
+                     float* gap_partial, int aligned_bf16, int weighted_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "tsum_forward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && logits_ld >= T && attn_ld >= T, "tsum_forward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && weighted_ld % 4 == 0 && aligned_ld >= T * C, "tsum_forward: ld");
     const dim3 grid(tsum_blocks_host(H, W), N);
-#define NVQ_TS(M_, U_, A_) hipLaunchKernelGGL((tsum_fwd_kernel<M_, U_, A_>), grid, dim3(256), 0, (hipStream_t)stream, aligned, aligned_ld, \
-                                              logits, logits_ld, T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, gap_partial)
-    if (T <= 4) { if (aligned_bf16) NVQ_TS(4, 4, true); else NVQ_TS(4, 4, false); }
-    else { if (aligned_bf16) NVQ_TS(NVQ_MAX_T, 2, true); else NVQ_TS(NVQ_MAX_T, 2, false); }
+#define NVQ_TS(M_, U_, A_, W_) hipLaunchKernelGGL((tsum_fwd_kernel<M_, U_, A_, W_>), grid, dim3(256), 0, (hipStream_t)stream, aligned, \
+                                                  aligned_ld, logits, logits_ld, T, C, (long)H * W, attn, attn_ld, weighted, weighted_ld, \
+                                                  gap_partial)
+#define NVQ_TS2(M_, U_) do { if (aligned_bf16) { if (weighted_bf16) NVQ_TS(M_, U_, true, true); else NVQ_TS(M_, U_, true, false); } \
+                             else { if (weighted_bf16) NVQ_TS(M_, U_, false, true); else NVQ_TS(M_, U_, false, false); } } while (0)
+    if (T <= 4) NVQ_TS2(4, 4); else NVQ_TS2(NVQ_MAX_T, 2);
+#undef NVQ_TS2
 #undef NVQ_TS
     return check_launch("tsum_forward");
 }
@@ -467,15 +474,16 @@ int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, 
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix, const float* aligned,
                       int aligned_ld, const float* attn, int attn_ld, int T, int C, int N, int H, int W,
                       float* daligned, int daligned_ld, float* dlogits, int dlogits_ld, int aligned_bf16,
-                      int daligned_bf16, void* stream) {
+                      int daligned_bf16, int dweighted_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C), "tsum_backward: C %d must be a power of two in [4,256]", C);
     NVQ_REQUIRE(T >= 1 && T <= NVQ_MAX_T && dlogits_ld >= T && attn_ld >= T, "tsum_backward: T %d", T);
     NVQ_REQUIRE(aligned_ld % 4 == 0 && dweighted_ld % 4 == 0 && daligned_ld % 4 == 0, "tsum_backward: ld");
     const long total = (long)N * H * W * (C / 4);
-#define NVQ_TB(A_) hipLaunchKernelGGL(tsum_bwd_kernel<A_>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dweighted, \
-                                      dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, daligned,         \
-                                      daligned_ld, dlogits, dlogits_ld, total, aligned_bf16, daligned_bf16)
-    if (aligned_bf16 && daligned_bf16) NVQ_TB(true); else NVQ_TB(false);
+#define NVQ_TB(A_, W_) hipLaunchKernelGGL((tsum_bwd_kernel<A_, W_>), dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,  \
+                                          dweighted, dweighted_ld, dgap_pix, aligned, aligned_ld, attn, attn_ld, T, C, (long)H * W, \
+                                          daligned, daligned_ld, dlogits, dlogits_ld, total, aligned_bf16, daligned_bf16)
+    if (aligned_bf16 && daligned_bf16) { if (dweighted_bf16) NVQ_TB(true, true); else NVQ_TB(true, false); }
+    else { if (dweighted_bf16) NVQ_TB(false, true); else NVQ_TB(false, false); }
 #undef NVQ_TB
     return check_launch("tsum_backward");
 }
@@ -489,17 +497,21 @@ int nvq_cbam_channel(const float* gap_partial, int nblk, int C, int R, int N, in
 }
 
 int nvq_cbam_pool(const float* x, int x_ld, const float* ca, int C, int N, int H, int W, float* sm, int* amax,
-                  void* stream) {
+                  int x_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C) && x_ld % 4 == 0, "cbam_pool: C %d must be a power of two in [4,256]", C);
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(cbam_pool_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, ca, C,
-                       (long)H * W, sm, amax, total);
+    if (x_bf16)
+        hipLaunchKernelGGL(cbam_pool_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, ca, C,
+                           (long)H * W, sm, amax, total);
+    else
+        hipLaunchKernelGGL(cbam_pool_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, ca, C,
+                           (long)H * W, sm, amax, total);
     return check_launch("cbam_pool");
 }
 
 int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const float* sm, const float* w7, int C,
                            int N, int H, int W, float* sa, float* out, int out_ld, int out_coff, int out_bf16,
-                           void* stream) {
+                           int x_bf16, void* stream) {
     NVQ_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0, "cbam_spatial_apply: alignment");
     const int tilesX = (W + SP_T - 1) / SP_T, tilesY = (H + SP_T - 1) / SP_T;
     hipStream_t s = (hipStream_t)stream;
@@ -507,19 +519,27 @@ int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const floa
     int rc = check_launch("cbam_sa");
     if (rc) return rc;
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(cbam_apply_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, x, x_ld, ca, sa, C, (long)H * W,
-                       out, out_ld, out_coff, out_bf16, total);
+    if (x_bf16)
+        hipLaunchKernelGGL(cbam_apply_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, s, x, x_ld, ca, sa, C, (long)H * W,
+                           out, out_ld, out_coff, out_bf16, total);
+    else
+        hipLaunchKernelGGL(cbam_apply_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, s, x, x_ld, ca, sa, C, (long)H * W,
+                           out, out_ld, out_coff, out_bf16, total);
     return check_launch("cbam_apply");
 }
 
 int nvq_cbam_bwd_spatial_pre(const float* dout, int dout_ld, int dout_coff, const float* x, int x_ld,
                              const float* ca, const float* sa, int C, int N, int H, int W, float* dpre,
-                             void* stream) {
+                             int x_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C) && x_ld % 4 == 0 && dout_ld % 4 == 0 && dout_coff % 4 == 0,
                 "cbam_bwd_spatial_pre: C %d must be a power of two in [4,256]", C);
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(cbam_bwd_pre_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
-                       dout_coff, x, x_ld, ca, sa, C, (long)H * W, dpre, total);
+    if (x_bf16)
+        hipLaunchKernelGGL(cbam_bwd_pre_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
+                           dout_coff, x, x_ld, ca, sa, C, (long)H * W, dpre, total);
+    else
+        hipLaunchKernelGGL(cbam_bwd_pre_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dout_ld,
+                           dout_coff, x, x_ld, ca, sa, C, (long)H * W, dpre, total);
     return check_launch("cbam_bwd_spatial_pre");
 }
 
@@ -538,11 +558,15 @@ int nvq_cbam_bwd_spatial_conv(const float* dpre, const float* sm, const float* w
 
 int nvq_cbam_bwd_scale(const float* dout, int dout_ld, int dout_coff, const float* x, int x_ld, const float* ca,
                        const float* sa, const float* dsm, const int* amax, int C, int N, int H, int W, float* dx,
-                       int dx_ld, float* dca_partial, void* stream) {
+                       int dx_ld, float* dca_partial, int x_bf16, void* stream) {
     NVQ_REQUIRE(pow2_c4(C) && x_ld % 4 == 0 && dout_ld % 4 == 0 && dout_coff % 4 == 0 && dx_ld % 4 == 0,
                 "cbam_bwd_scale: C %d must be a power of two in [4,256]", C);
-    hipLaunchKernelGGL(cbam_bwd_scale_kernel, dim3(tsum_blocks_host(H, W), N), dim3(256), 0, (hipStream_t)stream, dout,
-                       dout_ld, dout_coff, x, x_ld, ca, sa, dsm, amax, C, (long)H * W, dx, dx_ld, dca_partial);
+    if (x_bf16)
+        hipLaunchKernelGGL(cbam_bwd_scale_kernel<true>, dim3(tsum_blocks_host(H, W), N), dim3(256), 0, (hipStream_t)stream, dout,
+                           dout_ld, dout_coff, x, x_ld, ca, sa, dsm, amax, C, (long)H * W, dx, dx_ld, dca_partial);
+    else
+        hipLaunchKernelGGL(cbam_bwd_scale_kernel<false>, dim3(tsum_blocks_host(H, W), N), dim3(256), 0, (hipStream_t)stream, dout,
+                           dout_ld, dout_coff, x, x_ld, ca, sa, dsm, amax, C, (long)H * W, dx, dx_ld, dca_partial);
     return check_launch("cbam_bwd_scale");
 }
 

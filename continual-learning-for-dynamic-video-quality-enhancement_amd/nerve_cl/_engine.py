@@ -210,7 +210,13 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     K.conv_forward(Sl(a2), K.conv_pack(P["temporal_aggregator.attention.4.weight"], False, F, math=math),
                    P["temporal_aggregator.attention.4.bias"], Sl(logits, T), 3, cout_store=g.Tp, math=math)
     nblk = K.tsum_blocks(H, W)
-    attn, weighted = _new(dev, B, H, W, g.Tp), _new(dev, B, H, W, F)
+    # bf16 activation mode: the aggregated features (the CBAM's input; one write, four reads per step) and the two gradients around
+    # the CBAM backward are stored as bf16 like the tensors on either side of them; the pooled sums (GAP, channel mean / max,
+    # dca) are formed from the unrounded values inside the kernels.  NVQ_BF16_CBAM=0 keeps them fp32.
+    cbam16 = (act_dtype == torch.bfloat16 and math == K.MATH_BF16 and nblocks > 0
+              and os.environ.get("NVQ_BF16_CBAM", "1") != "0")
+    sv.cbam_dtype = torch.bfloat16 if cbam16 else torch.float32
+    attn, weighted = _new(dev, B, H, W, g.Tp), _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
     gap_partial = _new(dev, B, nblk, F)
     K.tsum_forward(aligned, logits, T, F, attn, weighted, gap_partial)
     gap, hid, ca = _new(dev, B, F), _new(dev, B, g.R), _new(dev, B, F)
@@ -329,7 +335,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
     # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
     dcats = [K.CatBuf(dev, B, H, W, F, LAYERS, g.CATLD, act_dtype, sv.planar) for _ in range(2)] if nb else []
-    dagg = _new(dev, B, H, W, F)
+    dagg = _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
     gout = dcats[(nb - 1) & 1].x() if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
     _capture("dfused", dfeat_c)
@@ -379,7 +385,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.cbam_bwd_spatial_pre(dprev, sv.weighted, sv.ca, sv.sa, dpre)
     dsm = _new(dev, B, H, W, 2)
     K.cbam_bwd_spatial_conv(dpre, sv.sm, w7, dsm, G["temporal_aggregator.refine.spatial_attention.conv.weight"], ws)
-    dweighted = _new(dev, B, H, W, F)
+    dweighted = _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
     dca_partial = _new(dev, B, sv.nblk, F)
     K.cbam_bwd_scale(dprev, sv.weighted, sv.ca, sv.sa, dsm, sv.amax, dweighted, dca_partial)
     dgap_pix = _new(dev, B, F)
@@ -404,7 +410,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F, math=math), None, Sl(daligned), 3,
                    accumulate=True, math=math)
     K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
-    _capture("dweighted", dweighted)
+    _capture("dweighted", lambda: dweighted.float())
     _capture("dlogits", dlogits)
     _capture("daligned", daligned)
 

@@ -99,14 +99,14 @@ SIGNATURES = {
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
-    "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]),
-    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, vp]),
+    "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, ci, vp]),
+    "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_cbam_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
-    "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]),
-    "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp]),
-    "nvq_cbam_bwd_spatial_pre": (ci, [vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "nvq_cbam_pool": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
+    "nvq_cbam_spatial_apply": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp]),
+    "nvq_cbam_bwd_spatial_pre": (ci, [vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, ci, vp]),
     "nvq_cbam_bwd_spatial_conv": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, sz, ci, vp]),
-    "nvq_cbam_bwd_scale": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "nvq_cbam_bwd_scale": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "nvq_cbam_bwd_channel": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "nvq_upsampler_tail_forward": (ci, [C.POINTER(ConvDesc), vp, ci, ci, ci, ci, vp, vp, vp]),
     "nvq_shuffle_bicubic_clamp": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
@@ -731,7 +731,7 @@ def tsum_forward(aligned: torch.Tensor, logits: torch.Tensor, T: int, Cc: int, a
     N, H, W, ld = aligned.shape
     check(lib().nvq_tsum_forward(ptr(aligned), ld, ptr(logits), logits.shape[-1], T, Cc, N, H, W, ptr(attn),
                                  attn.shape[-1], ptr(weighted), weighted.shape[-1], ptr(gap_partial), is_bf16(aligned),
-                                 stream()),
+                                 is_bf16(weighted), stream()),
           "nvq_tsum_forward")
 
 
@@ -739,7 +739,8 @@ def tsum_backward(dweighted, dgap_pix, aligned, attn, T: int, Cc: int, daligned,
     N, H, W, ld = aligned.shape
     check(lib().nvq_tsum_backward(ptr(dweighted), dweighted.shape[-1], ptr(dgap_pix), ptr(aligned), ld, ptr(attn),
                                   attn.shape[-1], T, Cc, N, H, W, ptr(daligned), daligned.shape[-1], ptr(dlogits),
-                                  dlogits.shape[-1], is_bf16(aligned), is_bf16(daligned), stream()), "nvq_tsum_backward")
+                                  dlogits.shape[-1], is_bf16(aligned), is_bf16(daligned), is_bf16(dweighted), stream()),
+          "nvq_tsum_backward")
 
 
 def cbam_channel(gap_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca):
@@ -749,20 +750,21 @@ def cbam_channel(gap_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca):
 
 def cbam_pool(x: torch.Tensor, ca, sm, amax):
     N, H, W, ld = x.shape
-    check(lib().nvq_cbam_pool(ptr(x), ld, ptr(ca), ca.shape[-1], N, H, W, ptr(sm), ptr(amax), stream()),
+    check(lib().nvq_cbam_pool(ptr(x), ld, ptr(ca), ca.shape[-1], N, H, W, ptr(sm), ptr(amax), is_bf16(x), stream()),
           "nvq_cbam_pool")
 
 
 def cbam_spatial_apply(x: torch.Tensor, ca, sm, w7, sa, out: Sl):
     N, H, W, ld = x.shape
     check(lib().nvq_cbam_spatial_apply(ptr(x), ld, ptr(ca), ptr(sm), ptr(w7), ca.shape[-1], N, H, W, ptr(sa),
-                                       ptr(out.t), out.ld, out.coff, out.bf16, stream()), "nvq_cbam_spatial_apply")
+                                       ptr(out.t), out.ld, out.coff, out.bf16, is_bf16(x), stream()), "nvq_cbam_spatial_apply")
 
 
 def cbam_bwd_spatial_pre(dout: Sl, x: torch.Tensor, ca, sa, dpre):
     N, H, W, ld = x.shape
+    assert dout.bf16 == is_bf16(x), "dout and x are stored alike"
     check(lib().nvq_cbam_bwd_spatial_pre(ptr(dout.t), dout.ld, dout.coff, ptr(x), ld, ptr(ca), ptr(sa),
-                                         ca.shape[-1], N, H, W, ptr(dpre), stream()), "nvq_cbam_bwd_spatial_pre")
+                                         ca.shape[-1], N, H, W, ptr(dpre), is_bf16(x), stream()), "nvq_cbam_bwd_spatial_pre")
 
 
 def cbam_bwd_spatial_conv(dpre, sm, w7, dsm, dw7, ws, accumulate=False):
@@ -773,9 +775,10 @@ def cbam_bwd_spatial_conv(dpre, sm, w7, dsm, dw7, ws, accumulate=False):
 
 def cbam_bwd_scale(dout: Sl, x: torch.Tensor, ca, sa, dsm, amax, dx: torch.Tensor, dca_partial):
     N, H, W, ld = x.shape
+    assert dout.bf16 == is_bf16(x) == is_bf16(dx), "dout, x and dx are stored alike"
     check(lib().nvq_cbam_bwd_scale(ptr(dout.t), dout.ld, dout.coff, ptr(x), ld, ptr(ca), ptr(sa), ptr(dsm),
                                    ptr(amax), ca.shape[-1], N, H, W, ptr(dx), dx.shape[-1], ptr(dca_partial),
-                                   stream()), "nvq_cbam_bwd_scale")
+                                   is_bf16(x), stream()), "nvq_cbam_bwd_scale")
 
 
 def cbam_bwd_channel(dca_partial, nblk, Cc, R, N, HW, w1, w2, gap, hid, ca, dw1, dw2, dgap_pix, accumulate=False):

@@ -332,14 +332,19 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
 int nvq_tsum_blocks(int H, int W);
 int nvq_tsum_forward(const float* aligned, int aligned_ld, const float* logits, int logits_ld,
                      int T, int C, int N, int H, int W, float* attn, int attn_ld,
-                     float* weighted, int weighted_ld, float* gap_partial, int aligned_bf16, void* stream);
-/* aligned_bf16 (here and below): `aligned` is stored as bf16 (aligned_ld counts bf16 elements); everything else is fp32. */
+                     float* weighted, int weighted_ld, float* gap_partial, int aligned_bf16, int weighted_bf16,
+                     void* stream);
+/* aligned_bf16 (here and below): `aligned` is stored as bf16 (aligned_ld counts bf16 elements).  weighted_bf16 /
+ * dweighted_bf16 / x_bf16 (here and in the CBAM calls below): the aggregated feature tensor `weighted` (= the CBAM's x), the
+ * gradient that enters the CBAM backward (dout) and the one that leaves it (dx = dweighted) are stored as bf16 - the bf16
+ * activation mode of the network; the pooled sums (gap_partial, sm, dca_partial) are formed from unrounded values either way. */
 /* dw = dweighted + dgap_pix[n][c] (dgap_pix may be NULL);
  * daligned[n,p,t*C+c] = dw*attn_t ; dlogits = softmax backward of sum_c dw*aligned_t. */
 int nvq_tsum_backward(const float* dweighted, int dweighted_ld, const float* dgap_pix,
                       const float* aligned, int aligned_ld, const float* attn, int attn_ld,
                       int T, int C, int N, int H, int W, float* daligned, int daligned_ld,
-                      float* dlogits, int dlogits_ld, int aligned_bf16, int daligned_bf16, void* stream);
+                      float* dlogits, int dlogits_ld, int aligned_bf16, int daligned_bf16, int dweighted_bf16,
+                      void* stream);
 
 /* CBAM, efficient_layers.py:154-228.
  * cbam_channel: gap = mean(weighted); hid = relu(W1 gap); ca = sigmoid(W2 hid).
@@ -349,17 +354,17 @@ int nvq_cbam_channel(const float* gap_partial, int nblk, int C, int R, int N, in
                      void* stream);
 /* sm[n,p,0] = mean_c(x*ca), sm[n,p,1] = max_c(x*ca); amax = argmax channel. sm ld = 2. */
 int nvq_cbam_pool(const float* x, int x_ld, const float* ca, int C, int N, int H, int W,
-                  float* sm, int* amax, void* stream);
+                  float* sm, int* amax, int x_bf16, void* stream);
 /* sa = sigmoid(conv7x7(sm; w[1][2][7][7], pad 3)); out = x*ca*sa written at (out,ld,coff); out_bf16 != 0
  * stores bf16 (the destination is the first dense block's concat buffer). */
 int nvq_cbam_spatial_apply(const float* x, int x_ld, const float* ca, const float* sm,
                            const float* w7, int C, int N, int H, int W, float* sa,
-                           float* out, int out_ld, int out_coff, int out_bf16, void* stream);
+                           float* out, int out_ld, int out_coff, int out_bf16, int x_bf16, void* stream);
 /* Backward through out = x*ca*sa:
  * step1: dpre[n,p] = (sum_c dout*x*ca) * sa*(1-sa)                                   */
 int nvq_cbam_bwd_spatial_pre(const float* dout, int dout_ld, int dout_coff, const float* x,
                              int x_ld, const float* ca, const float* sa, int C, int N,
-                             int H, int W, float* dpre, void* stream);
+                             int H, int W, float* dpre, int x_bf16, void* stream);
 /* step2: dsm = conv7x7^T(dpre) [N,H,W,2]; dw7[1][2][7][7] (+)= sum sm (*) dpre */
 int nvq_cbam_bwd_spatial_conv(const float* dpre, const float* sm, const float* w7, int N,
                               int H, int W, float* dsm, float* dw7, float* workspace,
@@ -369,7 +374,7 @@ int nvq_cbam_bwd_spatial_conv(const float* dpre, const float* sm, const float* w
 int nvq_cbam_bwd_scale(const float* dout, int dout_ld, int dout_coff, const float* x, int x_ld,
                        const float* ca, const float* sa, const float* dsm, const int* amax,
                        int C, int N, int H, int W, float* dx, int dx_ld, float* dca_partial,
-                       void* stream);
+                       int x_bf16, void* stream);
 /* step4: through sigmoid / FC / relu / FC / mean: dw1, dw2 (+)=; dgap_pix[n][c] = dgap/HW */
 int nvq_cbam_bwd_channel(const float* dca_partial, int nblk, int C, int R, int N, int HW,
                          const float* w1, const float* w2, const float* gap, const float* hid,
