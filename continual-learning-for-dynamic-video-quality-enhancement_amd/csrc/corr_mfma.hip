@@ -346,7 +346,7 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
                                                             int other_images, int H, int W, int tilesX, int tilesY,
                                                             float* __restrict__ dx, int dx_ld, int dx_coff,
                                                             int accumulate, int other_bf16, int groups, int group_images,
-                                                            __bf16* __restrict__ dx16, int dx16_ld) {
+                                                            __bf16* __restrict__ dx16, int dx16_ld, const nvq_corr_addends ad) {
     constexpr int YS = WHICH == 1 ? C + 8 : C + 16;
     constexpr int NCB = C / 16;
     constexpr int DPX = WHICH == 1 ? MT_H * MT_W : MHP;     // staged dcorr pixels: the tile / its halo
@@ -465,10 +465,30 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) old[cb] = ld4(op + cb * 16);
     }
+    // bf16 addends (the other terms of the gradient this pass finishes): raw 8-byte loads, all in flight before the first use
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    u2_t ra[NCB], rb[NCB];
+    const size_t apix = (size_t)(n0 * H + gy) * W + gx;
+    if (ad.a) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+            ra[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.a) + apix * ad.a_ld + ad.a_coff + cb * 16 + 4 * g);
+    }
+    if (ad.b) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+            rb[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.b) + apix * ad.b_ld + ad.b_coff + cb * 16 + 4 * g);
+    }
+    auto add_raw = [](float4& v, u2_t w) {
+        v.x += __uint_as_float(w[0] << 16); v.y += __uint_as_float(w[0] & 0xffff0000u);
+        v.z += __uint_as_float(w[1] << 16); v.w += __uint_as_float(w[1] & 0xffff0000u);
+    };
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
         if (accumulate) { v.x += old[cb].x; v.y += old[cb].y; v.z += old[cb].z; v.w += old[cb].w; }
+        if (ad.a) add_raw(v, ra[cb]);
+        if (ad.b) add_raw(v, rb[cb]);
         if (dx16)   // the last pass over an accumulated gradient: the sum leaves as bf16 (dx is only read)
             *reinterpret_cast<bf16x4*>(dx16 + ((size_t)(n0 * H + gy) * W + gx) * dx16_ld + cb * 16 + 4 * g) =
                 (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -507,14 +527,18 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
 
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       int other_bf16, int groups, float* dx16, int dx16_ld, hipStream_t s) {
+                       int other_bf16, int groups, float* dx16, int dx16_ld, const nvq_corr_addends* addends, hipStream_t s) {
+    const nvq_corr_addends ad = addends ? *addends : nvq_corr_addends{nullptr, 0, 0, nullptr, 0, 0};
+    NVQ_REQUIRE((!ad.a || (ad.a_ld % 4 == 0 && ad.a_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(ad.a) & 7) == 0)) &&
+                    (!ad.b || (ad.b_ld % 4 == 0 && ad.b_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(ad.b) & 7) == 0)),
+                "correlation_backward(bf16): addends need 8-byte aligned rows");
     NVQ_REQUIRE(!other_bf16 || other_ld % 8 == 0, "correlation_backward(bf16): a bf16 `other` needs ld %% 8 == 0");
     NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
                 "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \
-    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N, reinterpret_cast<__bf16*>(dx16), dx16_ld)
+    hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N, reinterpret_cast<__bf16*>(dx16), dx16_ld, ad)
 #define NVQ_CB2(CC) \
     do { if (which == 1) { if (dcorr_bf16) NVQ_CB(CC, 1, true); else NVQ_CB(CC, 1, false); } \
          else { if (dcorr_bf16) NVQ_CB(CC, 2, true); else NVQ_CB(CC, 2, false); } } while (0)

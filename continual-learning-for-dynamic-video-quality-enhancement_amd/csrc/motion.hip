@@ -623,7 +623,7 @@ int corr_forward_mfma(const float* x1, int x1_ld, const float* x2, int x2_ld, in
                       float* out, int out_ld, int out_bf16, int in_bf16, hipStream_t s);
 int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf16, const float* other, int other_ld,
                        int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
-                       int other_bf16, int groups, float* dx16, int dx16_ld, hipStream_t s);
+                       int other_bf16, int groups, float* dx16, int dx16_ld, const nvq_corr_addends* addends, hipStream_t s);
 
 }  // namespace nvq
 
@@ -651,7 +651,8 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const float* other, int other_ld,
                              int other_images, int C, int N, int H, int W, float* dx, int dx_ld, int dx_coff,
                              int accumulate, int math, int dcorr_bf16, int other_bf16, int groups, float* dx_bf16_out,
-                             int dx_bf16_ld, void* stream) {
+                             int dx_bf16_ld, const nvq_corr_addends* addends, void* stream) {
+    NVQ_REQUIRE(!addends || dx_bf16_out, "correlation_backward: bf16 addends go with the bf16 output");
     NVQ_REQUIRE(!dx_bf16_out || (math == NVQ_MATH_BF16 && corr_mfma_supported(C) && dx_bf16_ld % 4 == 0 && dx_bf16_ld >= C &&
                                  (reinterpret_cast<uintptr_t>(dx_bf16_out) & 7) == 0),
                 "correlation_backward: the bf16 output needs NVQ_MATH_BF16, C in {32, 64} and an 8-byte aligned row");
@@ -664,7 +665,7 @@ int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld, const 
     NVQ_REQUIRE(other_images > 0, "correlation_backward: other_images");
     if (math == NVQ_MATH_BF16 && corr_mfma_supported(C))
         return corr_backward_mfma(which, dcorr, dcorr_ld, dcorr_bf16, other, other_ld, other_images, C, N, H, W, dx, dx_ld,
-                                  dx_coff, accumulate, other_bf16, groups, dx_bf16_out, dx_bf16_ld, (hipStream_t)stream);
+                                  dx_coff, accumulate, other_bf16, groups, dx_bf16_out, dx_bf16_ld, addends, (hipStream_t)stream);
     NVQ_REQUIRE(!dcorr_bf16 && !other_bf16, "correlation_backward: bf16 tensors need NVQ_MATH_BF16 and C in {32, 64}");
     const int tilesX = (W + CT_W - 1) / CT_W, tilesY = (H + CT_H - 1) / CT_H;
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));

@@ -327,9 +327,15 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     # the centre frames' part is first written by the upsampler's input-gradient conv (out2 below), the other frames' by the
     # warp backward (overwrite mode); everything later is added to
     dfeat_c = dfeat_all[:B]
+    # bf16 activation mode with reference frames: the feature gradient is FINISHED by the two correlation gradients, which write it
+    # as bf16 (dfeat16, below).  The centre frames' three terms then never meet in an fp32 accumulator: this conv's second output
+    # and the attention path's slice of daligned are bf16 addends of that last pass (no axpy kernel, no read-modify-write).
+    feat16 = (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F in (32, 64) and sv.img8 is not None and NO > 0
+              and sv.aligned.dtype == torch.bfloat16 and os.environ.get("NVQ_BF16_FEATURE_GRAD", "1") != "0")
+    dfeat_c16 = _new(dev, B, H, W, F, dtype=torch.bfloat16) if feat16 else None
     dg = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
-                   out2=Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
+                   out2=Sl(dfeat_c16) if feat16 else Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
     # ---- gff
     xN = sv.xloc(nb)
     _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
@@ -338,7 +344,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dagg = _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
     gout = dcats[(nb - 1) & 1].x() if nb else Sl(dagg)
     K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
-    _capture("dfused", dfeat_c)
+    _capture("dfused", (lambda: dfeat_c16.float()) if feat16 else dfeat_c)
     _capture("dres", lambda: gout.t[..., :F].float())
 
     # ---- residual dense blocks, last to first, in mirror form (see nvq_rdb_backward_weights)
@@ -409,7 +415,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
     K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F, math=math), None, Sl(daligned), 3,
                    accumulate=True, math=math)
-    K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
+    if not feat16:
+        K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
     _capture("dweighted", lambda: dweighted.float())
     _capture("dlogits", dlogits)
     _capture("daligned", daligned)
@@ -452,15 +459,15 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         # sum as bf16 (dfeat16) instead of back into the fp32 accumulator - the extractor's backward reads it three times
         # (BatchNorm sums, pointwise backward, the skip add of the first depthwise layer) at half the bytes, like every other
         # gradient it consumes.
-        feat16 = (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F in (32, 64) and sv.img8 is not None
-                  and os.environ.get("NVQ_BF16_FEATURE_GRAD", "1") != "0")
         dfeat16 = _new(dev, NI, H, W, F, dtype=torch.bfloat16) if feat16 else None
         K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math, out16=dfeat16[B:] if feat16 else None)
-        # gradient w.r.t. the centre frame's features: the T - 1 reference frames in one pass (one read-modify-write)
-        K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), True, math=math, groups=T - 1,
-                               out16=dfeat16[:B] if feat16 else None)
+        # gradient w.r.t. the centre frame's features: the T - 1 reference frames in one pass
         if feat16:
+            K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), False, math=math, groups=T - 1, out16=dfeat16[:B],
+                                   addends=(Sl(dfeat_c16), Sl(daligned, F, c * F)))
             dfeat_all = dfeat16
+        else:
+            K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), True, math=math, groups=T - 1)
 
     # ---- feature extractor (all frames batched)
     _capture("dfeat_all", lambda: dfeat_all.float())

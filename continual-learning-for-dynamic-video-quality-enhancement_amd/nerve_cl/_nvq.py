@@ -50,6 +50,10 @@ class DwEpilogue(C.Structure):
     _fields_ = [("add", vp), ("add_ld", ci), ("mask", vp), ("mask_ld", ci), ("mask_bf16", ci), ("add_bf16", ci)]
 
 
+class CorrAddends(C.Structure):
+    _fields_ = [("a", vp), ("a_ld", ci), ("a_coff", ci), ("b", vp), ("b_ld", ci), ("b_coff", ci)]
+
+
 class BnInput(C.Structure):
     _fields_ = [("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp), ("group_images", ci)]
 
@@ -95,7 +99,7 @@ SIGNATURES = {
     "nvq_dwpw_forward": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cf, _IP, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_pw_bn_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
@@ -692,14 +696,23 @@ def correlation_forward(x1: Sl, x2: Sl, out: torch.Tensor, math: int = MATH_F32)
 
 
 def correlation_backward(which: int, dcorr: torch.Tensor, other: Sl, dx: Sl, accumulate: bool, math: int = MATH_F32,
-                         groups: int = 1, out16: Optional[torch.Tensor] = None):
+                         groups: int = 1, out16: Optional[torch.Tensor] = None, addends: Sequence[Sl] = ()):
     """groups > 1 (which == 2): dcorr / other hold groups * N images, frame-major; dx (N images) collects all of them in
-    one pass.  out16 (bf16 [N/groups, H, W, >= C]): the finished gradient is written there as bf16 instead of back to dx."""
+    one pass.  out16 (bf16 [N/groups, H, W, >= C]): the finished gradient is written there as bf16 instead of back to dx;
+    addends (with out16): up to two bf16 slices added in the same pass (accumulate False: dx is not read)."""
     N, H, W, ld = dcorr.shape
-    assert N % groups == 0 and (out16 is None or out16.dtype == torch.bfloat16)
+    assert N % groups == 0 and (out16 is None or out16.dtype == torch.bfloat16) and len(addends) <= 2
+    ad = None
+    if addends:
+        assert out16 is not None and all(a.bf16 for a in addends)
+        ad = CorrAddends()
+        ad.a, ad.a_ld, ad.a_coff = ptr(addends[0].t), addends[0].ld, addends[0].coff
+        if len(addends) > 1:
+            ad.b, ad.b_ld, ad.b_coff = ptr(addends[1].t), addends[1].ld, addends[1].coff
     check(lib().nvq_correlation_backward(which, ptr(dcorr), ld, other.base(), other.ld, other.n, other.c, N // groups, H, W,
                                          ptr(dx.t), dx.ld, dx.coff, int(accumulate), math, is_bf16(dcorr), other.bf16,
-                                         groups, ptr(out16), out16.shape[-1] if out16 is not None else 0, stream()),
+                                         groups, ptr(out16), out16.shape[-1] if out16 is not None else 0,
+                                         C.byref(ad) if ad is not None else None, stream()),
           "nvq_correlation_backward")
 
 

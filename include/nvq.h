@@ -298,12 +298,18 @@ int nvq_correlation_forward(const float* x1, int x1_ld, const float* x2, int x2_
  * math / dcorr_bf16 / other_bf16 as above; the bf16 path reads dcorr up to channel 96 (dcorr_ld >= 96).  dx is fp32.
  * dx_bf16_out != NULL (matrix-core path): this is the LAST pass over an accumulated gradient - the result (dx + the new
  * term when accumulate) is written as bf16 to dx_bf16_out [N,H,W,dx_bf16_ld] channels [0,C) instead of back to dx, which
- * is only read: the readers of the finished gradient then move half the bytes. */
+ * is only read: the readers of the finished gradient then move half the bytes.  addends (optional, with dx_bf16_out): up to
+ * two more terms of that gradient, bf16 tensors [N,H,W,ld] read at channels [coff, coff + C), added in the same pass (with
+ * accumulate == 0, dx is not touched at all - the whole sum is formed here, no fp32 accumulator, no separate add kernel). */
+typedef struct nvq_corr_addends {
+    const void* a; int a_ld; int a_coff;
+    const void* b; int b_ld; int b_coff;
+} nvq_corr_addends;
 int nvq_correlation_backward(int which, const float* dcorr, int dcorr_ld,
                              const float* other, int other_ld, int other_images, int C, int N,
                              int H, int W, float* dx, int dx_ld, int dx_coff, int accumulate,
                              int math, int dcorr_bf16, int other_bf16, int groups, float* dx_bf16_out, int dx_bf16_ld,
-                             void* stream);
+                             const nvq_corr_addends* addends, void* stream);
 
 /* warp_features, super_resolution.py:104-143 (F.grid_sample bilinear, zeros,
  * align_corners=True at pixel coordinates (x+flow_x, y+flow_y)). flow: [N,H,W,flow_ld>=2] fp32.

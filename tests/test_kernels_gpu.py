@@ -953,6 +953,14 @@ def test_correlation_mfma_forward_backward(K, C, B, R, H, W, store_bf16):
     o2 = torch.zeros(B, H, W, C, device="cuda", dtype=torch.bfloat16)
     K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(acc2), True, math=K.MATH_BF16, groups=R, out16=o2)
     assert torch.equal(o2, want2.bfloat16())
+    # ... and take the other terms of the sum as bf16 addends in the same pass (no fp32 accumulator at all)
+    ta = to_nhwc_bf16(bf(rnd(B, C, H, W, seed=12)))
+    tb = to_nhwc_bf16(bf(rnd(B, 3 * C, H, W, seed=13)))
+    o3 = torch.zeros(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+    K.correlation_backward(2, dcorr, K.Sl(x1b), K.Sl(acc2), False, math=K.MATH_BF16, groups=R, out16=o3,
+                           addends=(K.Sl(ta), K.Sl(tb, C, 2 * C)))
+    assert torch.equal(acc2, want2 * 0 + acc2)                # (dx untouched)
+    assert torch.equal(o3, (dx2m + ta.float() + tb[..., 2 * C:].float()).bfloat16())
 
 
 @pytest.mark.parametrize("C,B,R,H,W", [(64, 1, 2, 70, 20), (32, 2, 1, 45, 37), (64, 1, 1, 8, 16), (64, 1, 1, 131, 9)])
