@@ -369,33 +369,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
     wgrad_bias_partial(d, bsum, lds, nco, cic, coc);
 }
 
-// threads walk the partial layout (coalesced reads); the PyTorch-layout write is scattered once
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
-                                    int taps, int cout, int cin_w, float alpha, int accumulate,
-                                    float* __restrict__ dw) {
+// A 256-thread block owns WR_E consecutive elements of the partial layout (coalesced 128-byte reads); the nsplit slabs of an
+// element are shared out over WR_Q threads (slab k goes to thread k % WR_Q), whose double sums meet in LDS in a fixed order -
+// deterministic.  (One thread per element left a 192 -> 32 3x3 gradient with 216 workgroups and 170 dependent-latency-bound loads
+// per thread: 15 us per launch, 61 launches per step.)  The PyTorch-layout write is scattered once.
+constexpr int WR_Q = 8, WR_E = 256 / WR_Q;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
+                                                           int taps, int cout, int cin_w, float alpha, int accumulate,
+                                                           float* __restrict__ dw) {
+    __shared__ double sh[WR_Q][WR_E];
     const long total = (long)nci * nco * taps * WG_C * WG_C;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        long t = idx;
-        const int col = t % WG_C; t /= WG_C;
-        const int cil = t % WG_C; t /= WG_C;
-        const int tap = t % taps; t /= taps;
-        const int coc = t % nco;
-        const int cic = (int)(t / nco);
-        const int ci = cic * WG_C + cil, co = coc * WG_C + col;
-        if (ci >= cin_w || co >= cout) continue;
-        // 8 independent chains: the split loop is a chain of dependent HBM/L2 loads otherwise
-        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int k = 0;
-        for (; k + 8 <= nsplit; k += 8) {
+    const int e = threadIdx.x & (WR_E - 1), q = threadIdx.x / WR_E;
+    for (long base = (long)blockIdx.x * WR_E; base < total; base += (long)gridDim.x * WR_E) {   // (uniform trip count per block)
+        const long idx = base + e;
+        // 4 independent chains: the split loop is a chain of dependent HBM/L2 loads otherwise
+        double s4[4] = {0, 0, 0, 0};
+        if (idx < total) {
+            int k = q;
+            for (; k + 3 * WR_Q < nsplit; k += 4 * WR_Q) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += (double)part[(size_t)(k + u) * total + idx];
+                for (int u = 0; u < 4; ++u) s4[u] += (double)part[(size_t)(k + u * WR_Q) * total + idx];
+            }
+            for (; k < nsplit; k += WR_Q) s4[0] += (double)part[(size_t)k * total + idx];
         }
-        for (; k < nsplit; ++k) s8[0] += (double)part[(size_t)k * total + idx];
-        const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        const float v = alpha * (float)s;
-        const long o = ((long)co * cin_w + ci) * taps + tap;
-        dw[o] = accumulate ? dw[o] + v : v;
+        sh[q][e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        __syncthreads();
+        if (q == 0 && idx < total) {
+            double sum = 0.0;
+#pragma unroll
+            for (int u = 0; u < WR_Q; ++u) sum += sh[u][e];
+            long t = idx;
+            const int col = t % WG_C; t /= WG_C;
+            const int cil = t % WG_C; t /= WG_C;
+            const int tap = t % taps; t /= taps;
+            const int coc = t % nco;
+            const int cic = (int)(t / nco);
+            const int ci = cic * WG_C + cil, co = coc * WG_C + col;
+            if (ci < cin_w && co < cout) {
+                const float v = alpha * (float)sum;
+                const long o = ((long)co * cin_w + ci) * taps + tap;
+                dw[o] = accumulate ? dw[o] + v : v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -403,8 +419,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
 int launch_wgrad_reduce(const float* part, int nsplit, int nci, int nco, int taps, int cout, int cin_w, float alpha,
                         int accumulate, float* dw, hipStream_t s) {
     const long total = (long)nci * nco * taps * WG_C * WG_C;
-    int nblk = ceil_div(total, 256);
-    if (nblk > 2048) nblk = 2048;
+    int nblk = ceil_div(total, WR_E);
+    if (nblk > 4096) nblk = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, part, nsplit, nci, nco, taps, cout, cin_w, alpha,
                        accumulate, dw);
     return check_launch("conv_wgrad_reduce");
@@ -765,12 +781,7 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
         rc = check_launch("conv_wgrad");
     }
     if (rc) return rc;
-    const long total = (long)nci * nco * taps * WG_C * WG_C;
-    int nblk = ceil_div(total, 256);
-    if (nblk > 2048) nblk = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, d.workspace, nsplit, nci, nco,
-                       taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw);
-    rc = check_launch("conv_wgrad_reduce");
+    rc = launch_wgrad_reduce(d.workspace, nsplit, nci, nco, taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw, s);
     if (rc) return rc;
     if (d.dbias) {
         // bias_part[split][coc][32] written by the ci-chunk-0 workgroups; channel = coc*32 + lane
