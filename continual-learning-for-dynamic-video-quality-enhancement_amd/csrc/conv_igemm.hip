@@ -374,13 +374,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
 // deterministic.  (One thread per element left a 192 -> 32 3x3 gradient with 216 workgroups and 170 dependent-latency-bound loads
 // per thread: 15 us per launch, 61 launches per step.)  The PyTorch-layout write is scattered once.
 constexpr int WR_Q = 8, WR_E = 256 / WR_Q;
+// Blocks past `wblocks` do the bias gradient of the same launch (bp != NULL; one wave per output channel: bias_part[split][coc][32]
+// summed over the splits in double) - a launch of its own cost as much as its arithmetic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
                                                            int taps, int cout, int cin_w, float alpha, int accumulate,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, int wblocks, const float* __restrict__ bp,
+                                                           float* __restrict__ dbias) {
     __shared__ double sh[WR_Q][WR_E];
+    if ((int)blockIdx.x >= wblocks) {                         // (block-uniform)
+        const int co = ((int)blockIdx.x - wblocks) * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (co >= cout) return;
+        const int coc = co / WG_C, col = co % WG_C;
+        double s = 0.0;
+        for (int k = lane; k < nsplit; k += 64) s += (double)bp[((size_t)k * nco + coc) * WG_C + col];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            const float v = alpha * (float)s;
+            dbias[co] = accumulate ? dbias[co] + v : v;
+        }
+        return;
+    }
     const long total = (long)nci * nco * taps * WG_C * WG_C;
     const int e = threadIdx.x & (WR_E - 1), q = threadIdx.x / WR_E;
-    for (long base = (long)blockIdx.x * WR_E; base < total; base += (long)gridDim.x * WR_E) {   // (uniform trip count per block)
+    for (long base = (long)blockIdx.x * WR_E; base < total; base += (long)wblocks * WR_E) {     // (uniform trip count per block)
         const long idx = base + e;
         // 4 independent chains: the split loop is a chain of dependent HBM/L2 loads otherwise
         double s4[4] = {0, 0, 0, 0};
@@ -416,31 +433,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // (for kernels of other translation units that write partial slabs in this layout: pw_bwd.hip)
-int launch_wgrad_reduce(const float* part, int nsplit, int nci, int nco, int taps, int cout, int cin_w, float alpha,
-                        int accumulate, float* dw, hipStream_t s) {
+static int launch_wgrad_reduce_bias(const float* part, int nsplit, int nci, int nco, int taps, int cout, int cin_w, float alpha,
+                                    int accumulate, float* dw, const float* bias_part, float* dbias, hipStream_t s) {
     const long total = (long)nci * nco * taps * WG_C * WG_C;
     int nblk = ceil_div(total, WR_E);
     if (nblk > 4096) nblk = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, part, nsplit, nci, nco, taps, cout, cin_w, alpha,
-                       accumulate, dw);
+    const int bblk = dbias ? ceil_div(cout, 4) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk + bblk), dim3(256), 0, s, part, nsplit, nci, nco, taps, cout, cin_w, alpha,
+                       accumulate, dw, nblk, bias_part, dbias);
     return check_launch("conv_wgrad_reduce");
 }
-
-// one wave per output channel: sums bias_part[split][coc][32] over the splits in double
-__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bp, int nsplit, int nco,
-                                                                int cout, float alpha, int accumulate,
-                                                                float* __restrict__ dbias) {
-    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (co >= cout) return;
-    const int coc = co / WG_C, col = co % WG_C;
-    double s = 0.0;
-    for (int k = lane; k < nsplit; k += 64) s += (double)bp[((size_t)k * nco + coc) * WG_C + col];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) {
-        const float v = alpha * (float)s;
-        dbias[co] = accumulate ? dbias[co] + v : v;
-    }
+int launch_wgrad_reduce(const float* part, int nsplit, int nci, int nco, int taps, int cout, int cin_w, float alpha,
+                        int accumulate, float* dw, hipStream_t s) {
+    return launch_wgrad_reduce_bias(part, nsplit, nci, nco, taps, cout, cin_w, alpha, accumulate, dw, nullptr, nullptr, s);
 }
 
 // ---------------------------------------------------------------- column sums (bias gradient)
@@ -781,16 +786,9 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
         rc = check_launch("conv_wgrad");
     }
     if (rc) return rc;
-    rc = launch_wgrad_reduce(d.workspace, nsplit, nci, nco, taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw, s);
-    if (rc) return rc;
-    if (d.dbias) {
-        // bias_part[split][coc][32] written by the ci-chunk-0 workgroups; channel = coc*32 + lane
-        const float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(ceil_div(d.cout, 4)), dim3(256), 0, s, bp, nsplit, nco,
-                           d.cout, d.alpha, d.accumulate, d.dbias);
-        rc = check_launch("conv_wgrad_bias_reduce");
-    }
-    return rc;
+    // bias_part[split][coc][32] written by the ci-chunk-0 workgroups (channel = coc*32 + lane), reduced by the same launch
+    return launch_wgrad_reduce_bias(d.workspace, nsplit, nci, nco, taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw,
+                                    d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C, d.dbias, s);
 }
 
 int nvq_colsum(const float* x, int x_ld, int x_coff, int C, long npix, float alpha, float* out,
