@@ -47,6 +47,26 @@ def _capture(name: str, t) -> None:
         DEBUG_CAPTURE[name] = t.clone() if torch.is_tensor(t) else t
 
 
+class _Packs:
+    """The packed weights of one pass.  `prefetch` packs a list of (name, transpose, cin_store, keep) in one launch per 48 jobs
+    (K.conv_pack_many); `get` returns such a pack, or packs a single weight the list did not name."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], math: int):
+        self.P, self.math, self.done = P, math, {}
+
+    def prefetch(self, reqs) -> None:
+        reqs = [r for r in dict.fromkeys(reqs) if r not in self.done]
+        outs = K.conv_pack_many([(self.P[n], tr, cs, keep) for n, tr, cs, keep in reqs], self.math)
+        self.done.update(zip(reqs, outs))
+
+    def get(self, name: str, transpose: bool, cin_store: int, keep: Optional[int] = None) -> torch.Tensor:
+        key = (name, transpose, cin_store, keep)
+        wp = self.done.get(key)
+        if wp is None:
+            wp = self.done[key] = K.conv_pack(self.P[name], transpose, cin_store, keep, math=self.math)
+        return wp
+
+
 def workspace(device) -> torch.Tensor:
     ws = _ws_cache.get(device)
     if ws is None:
@@ -153,6 +173,19 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     ws = workspace(dev)
     sv = Saved()
     sv.g, sv.frames, sv.training, sv.math, sv.act_dtype = g, frames, training, math, act_dtype
+    # every forward weight pack of the step in two launches (57 single-pack launches otherwise)
+    packs = _Packs(P, math)
+    reqs = []
+    if NO:
+        reqs += [(f"motion_estimator.flow_net.{idx}.weight", False, cs, None)
+                 for idx, cs in zip((0, 2, 4, 6), (CORR_LD, K.pad4(128), K.pad4(64), K.pad4(32)))]
+    reqs += [("temporal_aggregator.attention.0.weight", False, T * F, None), ("temporal_aggregator.attention.2.weight", False, F, None),
+             ("temporal_aggregator.attention.4.weight", False, F, None)]
+    for k in range(nblocks):
+        reqs += [(f"residual_blocks.{k}.layers.{i}.0.weight", False, F + GROWTH * i, None) for i in range(LAYERS)]
+        reqs.append((f"residual_blocks.{k}.lff.weight", False, g.CAT, None))
+    reqs += [("gff.0.weight", False, F, None), ("upsampler.conv.weight", False, F, None)]
+    packs.prefetch(reqs)
 
     # ---- feature extractor, all T frames in one batch (slot order)
     # bf16 activation mode: the frames' features (`aligned`: centre frame + warped neighbours, `feat_oth`: the neighbours
@@ -187,7 +220,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         sv.flow_acts = [corr]
         for li, idx in enumerate((0, 2, 4, 6)):
             w = P[f"motion_estimator.flow_net.{idx}.weight"]
-            wp = K.conv_pack(w, False, x.c, math=math)
+            wp = packs.get(f"motion_estimator.flow_net.{idx}.weight", False, x.c)
             last = idx == 6
             y = _new(dev, NO, H, W, K.pad4(chans[li + 1]), dtype=torch.float32 if last else act_dtype)
             K.conv_forward(x, wp, P[f"motion_estimator.flow_net.{idx}.bias"], Sl(y, chans[li + 1]), 3,
@@ -203,11 +236,11 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     # ---- temporal aggregation
     a1, a2 = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)
     logits = _new(dev, B, H, W, g.Tp)
-    K.conv_forward(Sl(aligned), K.conv_pack(P["temporal_aggregator.attention.0.weight"], False, T * F, math=math),
+    K.conv_forward(Sl(aligned), packs.get("temporal_aggregator.attention.0.weight", False, T * F),
                    P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math)
-    K.conv_forward(Sl(a1), K.conv_pack(P["temporal_aggregator.attention.2.weight"], False, F, math=math),
+    K.conv_forward(Sl(a1), packs.get("temporal_aggregator.attention.2.weight", False, F),
                    P["temporal_aggregator.attention.2.bias"], Sl(a2), 3, relu=True, math=math)
-    K.conv_forward(Sl(a2), K.conv_pack(P["temporal_aggregator.attention.4.weight"], False, F, math=math),
+    K.conv_forward(Sl(a2), packs.get("temporal_aggregator.attention.4.weight", False, F),
                    P["temporal_aggregator.attention.4.bias"], Sl(logits, T), 3, cout_store=g.Tp, math=math)
     nblk = K.tsum_blocks(H, W)
     # bf16 activation mode: the aggregated features (the CBAM's input; one write, four reads per step) and the two gradients around
@@ -253,15 +286,15 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         cat = cats[k]
         for i in range(LAYERS - 1 if fuse_tail else LAYERS):
             cin = F + GROWTH * i
-            wp = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
+            wp = packs.get(f"residual_blocks.{k}.layers.{i}.0.weight", False, cin)
             K.conv_forward(cat.inp(cin), wp, P[f"residual_blocks.{k}.layers.{i}.0.bias"],
                            cat.y(i), 3, relu=True, math=math,
                            bits=sv.bits[k][i] if use_bits else None, bits_mode=1 if use_bits else 0)
-        wl = K.conv_pack(P[f"residual_blocks.{k}.lff.weight"], False, g.CAT, math=math)
+        wl = packs.get(f"residual_blocks.{k}.lff.weight", False, g.CAT)
         if fuse_tail:
             i = LAYERS - 1
             cin = F + GROWTH * i
-            w3 = K.conv_pack(P[f"residual_blocks.{k}.layers.{i}.0.weight"], False, cin, math=math)
+            w3 = packs.get(f"residual_blocks.{k}.layers.{i}.0.weight", False, cin)
             K.rdb_tail_forward(cat.inp(cin), w3, P[f"residual_blocks.{k}.layers.{i}.0.bias"], cat.y(i), wl,
                                P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), alpha=0.2, res=cat.x(),
                                bits=sv.bits[k][i] if use_bits else None)
@@ -272,11 +305,11 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     K.TIMER_TAG = ""
     # ---- global fusion + upsampler tail
     fused, gr = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)   # conv-to-conv tensors
-    K.conv_forward(xloc(nblocks), K.conv_pack(P["gff.0.weight"], False, F, math=math), P["gff.0.bias"], Sl(fused), 3,
+    K.conv_forward(xloc(nblocks), packs.get("gff.0.weight", False, F), P["gff.0.bias"], Sl(fused), 3,
                    relu=True, out2=Sl(gr), res=center, math=math)
     out = _new(dev, B, g.Cimg, H * scale, W * scale)
     passmask = _new(dev, B, g.Cimg, H * scale, W * scale, dtype=torch.uint8)
-    wup = K.conv_pack(P["upsampler.conv.weight"], False, F, math=math)
+    wup = packs.get("upsampler.conv.weight", False, F)
     if _fused_tail_ok(math, fused, g.Cimg, scale):
         # conv + pixel-shuffle (an LDS transpose in the conv's epilogue) + bicubic skip + clamp: one launch, no `u` tensor
         K.upsampler_tail_forward(Sl(fused), wup, P["upsampler.conv.bias"], frames, c, scale, out, passmask)
@@ -318,6 +351,16 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     math, act_dtype = sv.math, sv.act_dtype
     ws = workspace(dev)
     nb = g.NB
+    # the transposed packs of the input-gradient convs outside the dense blocks in one launch (the blocks' mirror-form packs
+    # have a batched launch of their own below)
+    packs = _Packs(P, math)
+    pre_a = "temporal_aggregator.attention."
+    reqs = [("upsampler.conv.weight", True, g.Up, F), ("gff.0.weight", True, F, F), (pre_a + "4.weight", True, g.Tp, F),
+            (pre_a + "2.weight", True, F, F), (pre_a + "0.weight", True, F, T * F)]
+    if NO:
+        reqs += [(f"motion_estimator.flow_net.{idx}.weight", True, cs, keep)
+                 for idx, cs, keep in zip((6, 4, 2, 0), (4, K.pad4(32), K.pad4(64), K.pad4(128)), (32, 64, 128, 81))]
+    packs.prefetch(reqs)
 
     # ---- upsampler tail
     du = _new(dev, B, H, W, g.Up)
@@ -334,7 +377,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
               and sv.aligned.dtype == torch.bfloat16 and os.environ.get("NVQ_BF16_FEATURE_GRAD", "1") != "0")
     dfeat_c16 = _new(dev, B, H, W, F, dtype=torch.bfloat16) if feat16 else None
     dg = _new(dev, B, H, W, F, dtype=act_dtype)
-    K.conv_forward(Sl(du), K.conv_pack(P["upsampler.conv.weight"], True, g.Up, F, math=math), None, Sl(dg), 3,
+    K.conv_forward(Sl(du), packs.get("upsampler.conv.weight", True, g.Up, F), None, Sl(dg), 3,
                    out2=Sl(dfeat_c16) if feat16 else Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
     # ---- gff
     xN = sv.xloc(nb)
@@ -343,7 +386,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dcats = [K.CatBuf(dev, B, H, W, F, LAYERS, g.CATLD, act_dtype, sv.planar) for _ in range(2)] if nb else []
     dagg = _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
     gout = dcats[(nb - 1) & 1].x() if nb else Sl(dagg)
-    K.conv_forward(Sl(dg), K.conv_pack(P["gff.0.weight"], True, F, F, math=math), None, gout, 3, math=math)
+    K.conv_forward(Sl(dg), packs.get("gff.0.weight", True, F, F), None, gout, 3, math=math)
     _capture("dfused", (lambda: dfeat_c16.float()) if feat16 else dfeat_c)
     _capture("dres", lambda: gout.t[..., :F].float())
 
@@ -406,14 +449,14 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     pre = "temporal_aggregator.attention."
     _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", ws, 3, math=math)
     da2 = _new(dev, B, H, W, F, dtype=act_dtype)
-    K.conv_forward(Sl(dlogits), K.conv_pack(P[pre + "4.weight"], True, g.Tp, F, math=math), None, Sl(da2), 3,
+    K.conv_forward(Sl(dlogits), packs.get(pre + "4.weight", True, g.Tp, F), None, Sl(da2), 3,
                    mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
     da1 = _new(dev, B, H, W, F, dtype=act_dtype)
-    K.conv_forward(Sl(da2), K.conv_pack(P[pre + "2.weight"], True, F, F, math=math), None, Sl(da1), 3,
+    K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3,
                    mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
-    K.conv_forward(Sl(da1), K.conv_pack(P[pre + "0.weight"], True, F, T * F, math=math), None, Sl(daligned), 3,
+    K.conv_forward(Sl(da1), packs.get(pre + "0.weight", True, F, T * F), None, Sl(daligned), 3,
                    accumulate=True, math=math)
     if not feat16:
         K.axpy_slice(Sl(dfeat_c), Sl(daligned, F, c * F))
@@ -439,7 +482,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             x_sl = Sl(x_t) if li > 0 else Sl(x_t, CORR_LD, 0)
             _wgrad(x_sl, chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
             cin_store = dy_t.shape[-1]
-            wp = K.conv_pack(P[name + "weight"], True, cin_store, chans[li], math=math)
+            wp = packs.get(name + "weight", True, cin_store, chans[li])
             dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else x_t.dtype)
             if li > 0:
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
