@@ -467,8 +467,32 @@ __global__ __launch_bounds__(256) void warp_bwd_src_kernel(const float* __restri
     }
 }
 
+// dst[0..3] += v for an fp32 or a bf16-stored gradient.  bf16: a compare-and-swap loop on each 32-bit word (two bf16 values);
+// only the rare paths use it (far sources, hit-list overflow).
+template <bool FB16>
+__device__ __forceinline__ void warp_atomic_add4(float* base, size_t idx, float4 v) {
+    if constexpr (!FB16) {
+        float* p = base + idx;
+        atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+    } else {
+        unsigned* w = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(base) + idx);     // idx % 4 == 0: 8-byte aligned
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float a = h ? v.z : v.x, b = h ? v.w : v.y;
+            unsigned old = w[h], assumed;
+            do {
+                assumed = old;
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                const b2 pk = {(__bf16)(__uint_as_float(assumed << 16) + a), (__bf16)(__uint_as_float(assumed & 0xffff0000u) + b)};
+                old = atomicCAS(w + h, assumed, __builtin_bit_cast(unsigned, pk));
+            } while (old != assumed);
+        }
+    }
+}
+
 // Overwrite mode, behind the gather pass: the sources the window cannot reach (|flow| >= 4 px), scattered with atomics as the
 // src pass does in the accumulate mode.  Leaves at once when the src pass flagged none (the usual case).
+template <bool FB16>                                          // FB16: dfeat is stored as bf16
 __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                            const float* __restrict__ flow, int flow_ld, int C, int H, int W,
                                                            float* __restrict__ dfeat, int dfeat_ld, long npix, int dout_bf16,
@@ -489,8 +513,7 @@ __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restri
         const float4 go = ldx4(dout, (size_t)pix * dout_ld + dout_coff + ch, dout_bf16);
         auto corner = [&](bool valid, long o, float wgt) {
             if (!valid) return;
-            float* db = dfeat + o * dfeat_ld + ch;
-            atomicAdd(db, go.x * wgt); atomicAdd(db + 1, go.y * wgt); atomicAdd(db + 2, go.z * wgt); atomicAdd(db + 3, go.w * wgt);
+            warp_atomic_add4<FB16>(dfeat, (size_t)o * dfeat_ld + ch, make_float4(go.x * wgt, go.y * wgt, go.z * wgt, go.w * wgt));
         };
         corner(g.vnw, img + (long)g.y0 * W + g.x0, g.wnw);
         corner(g.vne, img + (long)g.y0 * W + g.x0 + 1, g.wne);
@@ -504,7 +527,7 @@ __global__ __launch_bounds__(256) void warp_bwd_far_kernel(const float* __restri
 // each, so a pixel's 64 channels are one coalesced 256-byte access) walk the lists and add into dfeat.
 constexpr int WG_MAXHIT = 12;                   // list length per pixel; further hits (a strongly contracting flow) are
                                                 // applied by phase 1 itself, one pixel per lane
-template <bool DB>
+template <bool DB, bool FB16>                                 // DB: dout is bf16; FB16: dfeat is bf16
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __restrict__ dout, int dout_ld, int dout_coff,
                                                               const float4* __restrict__ rec_w,
                                                               const int* __restrict__ rec_code, int C, int H, int W,
@@ -587,13 +610,13 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                     acc.x += wv[u] * v[u].x; acc.y += wv[u] * v[u].y; acc.z += wv[u] * v[u].z; acc.w += wv[u] * v[u].w;
                 }
             }
-            float* dst = dfeat + qpix * dfeat_ld + ch;
+            const size_t di = (size_t)qpix * dfeat_ld + ch;
             if (overwrite) {                                  // the first writer of dfeat: every pixel of the tile is written
-                st4(dst, acc);
+                stx4(dfeat, di, FB16, acc);
             } else {
-                float4 o = ld4(dst);
+                float4 o = ldx4(dfeat, di, FB16);
                 o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-                st4(dst, o);
+                stx4(dfeat, di, FB16, o);
             }
         }
     }
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
     // phase 2's write of that pixel (still no atomics: q is ours)
     if (__syncthreads_or(total1 > WG_MAXHIT)) {
         if (total1 > WG_MAXHIT) {
-            float* dst = dfeat + ((long)(n * H + qy1) * W + qx1) * dfeat_ld;
+            const size_t dbase = ((size_t)(n * H + qy1) * W + qx1) * dfeat_ld;
             scan(ly1, lx1, [&](int k, int sy, int sx, float wgt) {
                 if (k < WG_MAXHIT) return;
                 const size_t so = ((size_t)(n * H + qy1 + sy) * W + qx1 + sx) * dout_ld + dout_coff;
@@ -609,8 +632,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* __res
                     const float4 v = ldx4(dout, so + ch, dout_bf16);
                     // (atomics only for their L2 scope - phase 2 wrote this pixel from another wave; one thread per pixel, in
                     // scan order: still deterministic)
-                    atomicAdd(dst + ch, wgt * v.x); atomicAdd(dst + ch + 1, wgt * v.y);
-                    atomicAdd(dst + ch + 2, wgt * v.z); atomicAdd(dst + ch + 3, wgt * v.w);
+                    warp_atomic_add4<FB16>(dfeat, dbase + ch, make_float4(wgt * v.x, wgt * v.y, wgt * v.z, wgt * v.w));
                 }
             });
         }
@@ -701,7 +723,8 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat, int feat_ld,
                       const float* flow, int flow_ld, int C, int N, int H, int W, float* dfeat, int dfeat_ld,
                       float* dflow, int dflow_ld, float* records, size_t records_bytes, int feat_bf16, int dout_bf16,
-                      int overwrite, void* stream) {
+                      int overwrite, int dfeat_bf16, void* stream) {
+    NVQ_REQUIRE(!dfeat_bf16 || (records && overwrite), "warp_backward: a bf16 dfeat needs the gather form in the overwrite mode");
     NVQ_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "warp_backward: C %d must be a power of two >= 4", C);
     NVQ_REQUIRE(!(feat_bf16 || dout_bf16) || records, "warp_backward: bf16-stored tensors need the gather form (records != NULL)");
     NVQ_REQUIRE(flow_ld >= 2 && dflow_ld >= 2, "warp_backward: flow ld");
@@ -728,16 +751,20 @@ int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float
 #undef NVQ_WS
         int rc = check_launch("warp_backward(src)");
         if (rc) return rc;
-        if (dout_bf16)
-            hipLaunchKernelGGL(warp_bwd_gather_kernel<true>, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout,
-                               dout_ld, dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, overwrite);
-        else
-            hipLaunchKernelGGL(warp_bwd_gather_kernel<false>, dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, dout,
-                               dout_ld, dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, overwrite);
+#define NVQ_WG(D_, F_) hipLaunchKernelGGL((warp_bwd_gather_kernel<D_, F_>), dim3((unsigned)((long)tilesX * tilesY * N)), dim3(256), 0, s, \
+                                          dout, dout_ld, dout_coff, rec_w, rec_code, C, H, W, tilesX, tilesY, dfeat, dfeat_ld, overwrite)
+        if (dout_bf16) { if (dfeat_bf16) NVQ_WG(true, true); else NVQ_WG(true, false); }
+        else { if (dfeat_bf16) NVQ_WG(false, true); else NVQ_WG(false, false); }
+#undef NVQ_WG
         rc = check_launch("warp_backward(gather)");
         if (rc || !overwrite) return rc;
-        hipLaunchKernelGGL(warp_bwd_far_kernel, dim3(ceil_div(npix, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
+if (dfeat_bf16) {
+                    hipLaunchKernelGGL(warp_bwd_far_kernel<true>, dim3(ceil_div(npix, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
                            flow_ld, C, H, W, dfeat, dfeat_ld, npix, dout_bf16, far_flag);
+        } else {
+                    hipLaunchKernelGGL(warp_bwd_far_kernel<false>, dim3(ceil_div(npix, 256)), dim3(256), 0, s, dout, dout_ld, dout_coff, flow,
+                           flow_ld, C, H, W, dfeat, dfeat_ld, npix, dout_bf16, far_flag);
+        }
         return check_launch("warp_backward(far)");
     }
     NVQ_REQUIRE(!overwrite, "warp_backward: the overwrite mode needs the gather form (records != NULL)");

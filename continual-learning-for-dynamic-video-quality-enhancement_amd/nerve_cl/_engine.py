@@ -366,15 +366,16 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     du = _new(dev, B, H, W, g.Up)
     K.shuffle_clamp_backward(dout, sv.passmask, g.s, du)
     _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", ws, 3, math=math)
-    dfeat_all = _new(dev, NI, H, W, F)              # gradient w.r.t. the features of every frame (slot order)
-    # the centre frames' part is first written by the upsampler's input-gradient conv (out2 below), the other frames' by the
-    # warp backward (overwrite mode); everything later is added to
-    dfeat_c = dfeat_all[:B]
     # bf16 activation mode with reference frames: the feature gradient is FINISHED by the two correlation gradients, which write it
-    # as bf16 (dfeat16, below).  The centre frames' three terms then never meet in an fp32 accumulator: this conv's second output
-    # and the attention path's slice of daligned are bf16 addends of that last pass (no axpy kernel, no read-modify-write).
+    # as bf16 (dfeat16, below).  Its terms then never meet in an fp32 accumulator: the upsampler input-gradient conv's second
+    # output, the attention path's slice of daligned and the warp gradient are bf16 addends of those last passes (no fp32
+    # gradient tensor, no axpy kernel, no read-modify-write).
     feat16 = (math == K.MATH_BF16 and act_dtype == torch.bfloat16 and F in (32, 64) and sv.img8 is not None and NO > 0
               and sv.aligned.dtype == torch.bfloat16 and os.environ.get("NVQ_BF16_FEATURE_GRAD", "1") != "0")
+    # fp32 form: gradient w.r.t. the features of every frame (slot order); the centre frames' part is first written by the
+    # upsampler's input-gradient conv (out2 below), the other frames' by the warp backward (overwrite mode), the rest added
+    dfeat_all = _new(dev, B if feat16 else NI, 1 if feat16 else H, 1 if feat16 else W, F)   # (feat16: only a pointer for unused arguments)
+    dfeat_c = dfeat_all[:B]
     dfeat_c16 = _new(dev, B, H, W, F, dtype=torch.bfloat16) if feat16 else None
     dg = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(du), packs.get("upsampler.conv.weight", True, g.Up, F), None, Sl(dg), 3,
@@ -466,7 +467,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
 
     # ---- motion: warp, flow net, correlation
     if NO:
-        dfeat_oth = dfeat_all[B:]
+        # (feat16: the reference frames' term from the warp leaves as bf16 too and is an addend of the correlation gradient's pass)
+        dfeat_oth = _new(dev, NO, H, W, F, dtype=torch.bfloat16) if feat16 else dfeat_all[B:]
         dflow = _new(dev, NO, H, W, 4)
         for j in range(1, T):
             t = g.slots[j]
@@ -503,7 +505,10 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         # (BatchNorm sums, pointwise backward, the skip add of the first depthwise layer) at half the bytes, like every other
         # gradient it consumes.
         dfeat16 = _new(dev, NI, H, W, F, dtype=torch.bfloat16) if feat16 else None
-        K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math, out16=dfeat16[B:] if feat16 else None)
+        if feat16:
+            K.correlation_backward(1, dcorr, center, Sl(dfeat_c), False, math=math, out16=dfeat16[B:], addends=(Sl(dfeat_oth),))
+        else:
+            K.correlation_backward(1, dcorr, center, Sl(dfeat_oth), True, math=math)
         # gradient w.r.t. the centre frame's features: the T - 1 reference frames in one pass
         if feat16:
             K.correlation_backward(2, dcorr, Sl(sv.feat_oth), Sl(dfeat_c), False, math=math, groups=T - 1, out16=dfeat16[:B],

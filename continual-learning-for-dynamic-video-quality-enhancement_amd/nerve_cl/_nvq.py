@@ -101,7 +101,7 @@ SIGNATURES = {
     "nvq_correlation_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
     "nvq_correlation_backward": (ci, [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp, vp]),
     "nvq_warp_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp]),
-    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, vp]),
+    "nvq_warp_backward": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, sz, ci, ci, ci, ci, vp]),
     "nvq_tsum_blocks": (ci, [ci, ci]),
     "nvq_tsum_forward": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, ci, vp]),
     "nvq_tsum_backward": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, vp]),
@@ -731,7 +731,7 @@ def warp_backward(dout: Sl, feat: Sl, flow: torch.Tensor, dfeat: Sl, dflow: torc
     check(lib().nvq_warp_backward(ptr(dout.t), dout.ld, dout.coff, feat.base(), feat.ld, ptr(flow),
                                   flow.shape[-1], feat.c, N, H, W, dfeat.base(), dfeat.ld, ptr(dflow),
                                   dflow.shape[-1], ptr(rec), rec.numel() * 4 if rec is not None else 0, feat.bf16, dout.bf16,
-                                  int(overwrite), stream()),
+                                  int(overwrite), dfeat.bf16, stream()),
           "nvq_warp_backward")
 
 

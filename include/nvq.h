@@ -324,11 +324,13 @@ int nvq_warp_forward(const float* feat, int feat_ld, const float* flow, int flow
  * 4 weights} record, a per-destination pass collects the contributions from the 9x9 window around each pixel; no atomics
  * and a fixed summation order for every source whose flow is shorter than 4 pixels (longer ones are still scattered).
  * feat_bf16 / dout_bf16: `feat` (read for the flow gradient) / `dout` are stored as bf16 - gather form only; dfeat and
- * dflow are fp32. */
+ * dflow are fp32 - except dfeat in the overwrite mode with dfeat_bf16 != 0: the gather pass then writes bf16 (the far sources
+ * and the hit-list overflow add with a compare-and-swap loop per 32-bit word). */
 int nvq_warp_backward(const float* dout, int dout_ld, int dout_coff, const float* feat,
                       int feat_ld, const float* flow, int flow_ld, int C, int N, int H, int W,
                       float* dfeat, int dfeat_ld, float* dflow, int dflow_ld,
-                      float* records, size_t records_bytes, int feat_bf16, int dout_bf16, int overwrite, void* stream);
+                      float* records, size_t records_bytes, int feat_bf16, int dout_bf16, int overwrite, int dfeat_bf16,
+                      void* stream);
 
 /* ------------------------------------------------------------------ temporal aggregation
  * TemporalAggregator.forward softmax + weighted sum, super_resolution.py:174,203-204:

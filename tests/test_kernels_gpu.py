@@ -349,6 +349,10 @@ def test_warp_forward_backward(K, C, N, H, W, mag, gather):
         dflow2 = torch.empty(N, H, W, 4, device="cuda")
         K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat2), dflow2, overwrite=True)
         assert rel(from_nhwc(dfeat2), feat.grad) < 5e-5 and torch.equal(dflow2, dflow)
+        # ... and as bf16 (far sources then add with a compare-and-swap loop per word: rounded after every add)
+        dfeat3 = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat3), dflow2, overwrite=True)
+        assert rel(from_nhwc(dfeat3.float()), feat.grad) < (8e-3 if mag < 4 else 3e-2) and torch.equal(dflow2, dflow)
     else:
         with pytest.raises(RuntimeError, match="overwrite mode needs the gather form"):
             K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat), dflow, gather=False, overwrite=True)
@@ -374,6 +378,10 @@ def test_warp_backward_contracting_flow_overflows_the_hit_list(K, overwrite):
     got = from_nhwc(dfeat) - (0 if overwrite else base)
     assert rel(got, feat.grad) < 5e-5
     assert rel(from_nhwc(dflow, 2), flow.grad) < 2e-4
+    if overwrite:                                             # bf16 dfeat: the overflow adds round after every term
+        d16 = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+        K.warp_backward(K.Sl(dal), K.Sl(to_nhwc(feat.detach())), to_nhwc(flow.detach(), 4), K.Sl(d16), dflow, overwrite=True)
+        assert rel(from_nhwc(d16.float()), feat.grad) < 3e-2
 
 
 # ----------------------------------------------------------------------------- aggregation
