@@ -120,10 +120,13 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                 res4[k][slot] = ld_raw4(d.res, pixv[pb] * d.res_ld + d.res_coff + (cov[cb0 + k] < d.res_cmax ? cov[cb0 + k] : 0),
                                         d.res_bf16);
         };
+        // one-bit ReLU masks: word (cz * NT) / 32 of the pixel's bits_words words (a wave's channels lie in one word: NT = 32, or
+        // NT = 16 with a single channel chunk), bit = channel % 32
+        const int bw = d.bits_words > 0 ? d.bits_words : 1, wsel = (cz * NT) >> 5;
         if constexpr (NB <= 2) {
             if (d.bits_mode == 2) {
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb) bits_in[pb] = d.bits[pixv[pb]];
+                for (int pb = 0; pb < 4; ++pb) bits_in[pb] = d.bits[pixv[pb] * bw + wsel];
             }
         }
         if constexpr (FULL) {
@@ -189,10 +192,10 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                     if (d.bits_mode == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (!((bits_in[pb] >> (co + e)) & 1u)) v[e] = 0.f;
+                            if (!((bits_in[pb] >> ((co & 31) + e)) & 1u)) v[e] = 0.f;
                     } else if (d.bits_mode == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << (co + e);
+                        for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << ((co & 31) + e);
                     }
                 }
                 if (stage)
@@ -205,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                 if (d.bits_mode == 1) {                // OR over the 4 lanes (g) of this pixel, lane g = 0 stores the word
                     bits_out |= __shfl_xor(bits_out, 16, 64);
                     bits_out |= __shfl_xor(bits_out, 32, 64);
-                    if (g == 0) d.bits[pix] = bits_out;
+                    if (g == 0) d.bits[pix * bw + wsel] = bits_out;
                 }
             }
         }

@@ -690,9 +690,12 @@ int nvq_conv_forward(const nvq_conv_desc* dp, void* stream) {
                  (d.cout % 4 == 0 || !d.bias);
     if (d.bias && !aligned16(d.bias)) vec_ok = 0;
     if (d.bits_mode != 0)
-        NVQ_REQUIRE((d.bits_mode == 1 || d.bits_mode == 2) && d.bits && d.math == NVQ_MATH_BF16 && NT <= 32 && ncz == 1 &&
-                        vec_ok && !d.mask && !d.res && !d.accumulate && !d.out2,
-                    "conv_forward: bit masks need NVQ_MATH_BF16, cout <= 32 and a plain vector epilogue");
+        NVQ_REQUIRE((d.bits_mode == 1 || d.bits_mode == 2) && d.bits && d.math == NVQ_MATH_BF16 &&
+                        ((NT <= 32 && ncz == 1) || (NT == 64 && d.ksize == 3 && d.in_bf16 && d.tile_rows != 8)) &&
+                        (d.bits_words > 0 ? d.bits_words : 1) * 32 >= d.cout_store && vec_ok && !d.mask && !d.res &&
+                        !d.accumulate && !d.out2,
+                    "conv_forward: bit masks need NVQ_MATH_BF16, a plain vector epilogue and cout <= 32 (or a 3x3 conv of a bf16 "
+                    "input), bits_words * 32 >= cout_store");
     if (d.out2 && !(d.out2_ld % 4 == 0 && d.out2_coff % 4 == 0 && aligned16(d.out2))) vec_ok = 0;
     if (d.res && !(d.res_ld % 4 == 0 && d.res_coff % 4 == 0 && d.res_cmax % 4 == 0 && aligned16(d.res))) vec_ok = 0;
     if (d.mask && !(d.mask_ld % 4 == 0 && d.mask_coff % 4 == 0 && d.mask_c0 % 4 == 0 &&

@@ -218,14 +218,23 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
         chans = [81, 128, 64, 32, 2]
         x = Sl(corr, CORR_LD, 0)
         sv.flow_acts = [corr]
+        # bf16 mode, training: the hidden layers also leave their ReLU masks as one bit per channel (the input-gradient conv of the
+        # layer behind reads 4 bytes per 32 channels instead of the 64-byte activations, as in the dense blocks)
+        act_bits = (training and act_dtype == torch.bfloat16 and math == K.MATH_BF16
+                    and os.environ.get("NVQ_RELU_BITS", "1") != "0")
+        sv.flow_bits = [None] * 5
         for li, idx in enumerate((0, 2, 4, 6)):
             w = P[f"motion_estimator.flow_net.{idx}.weight"]
             wp = packs.get(f"motion_estimator.flow_net.{idx}.weight", False, x.c)
             last = idx == 6
             y = _new(dev, NO, H, W, K.pad4(chans[li + 1]), dtype=torch.float32 if last else act_dtype)
+            # (more than 32 output channels: only the channel-split kernel of a bf16 input writes bits)
+            bits = (_new(dev, NO, H, W, chans[li + 1] // 32, dtype=torch.int32)
+                    if (act_bits and not last and (x.bf16 or chans[li + 1] <= 32)) else None)
             K.conv_forward(x, wp, P[f"motion_estimator.flow_net.{idx}.bias"], Sl(y, chans[li + 1]), 3,
-                           relu=not last, cout_store=K.pad4(chans[li + 1]), math=math)
+                           relu=not last, cout_store=K.pad4(chans[li + 1]), math=math, bits=bits, bits_mode=1 if bits is not None else 0)
             sv.flow_acts.append(y)
+            sv.flow_bits[li + 1] = bits
             x = Sl(y)
         flow = sv.flow_acts[-1]
         for j in range(1, T):
@@ -236,8 +245,12 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
     # ---- temporal aggregation
     a1, a2 = _new(dev, B, H, W, F, dtype=act_dtype), _new(dev, B, H, W, F, dtype=act_dtype)
     logits = _new(dev, B, H, W, g.Tp)
+    sv.a1_bits = (_new(dev, B, H, W, F // 32, dtype=torch.int32)
+                  if (training and act_dtype == torch.bfloat16 and math == K.MATH_BF16 and F % 32 == 0
+                      and (aligned.dtype == torch.bfloat16 or F <= 32) and os.environ.get("NVQ_RELU_BITS", "1") != "0") else None)
     K.conv_forward(Sl(aligned), packs.get("temporal_aggregator.attention.0.weight", False, T * F),
-                   P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math)
+                   P["temporal_aggregator.attention.0.bias"], Sl(a1), 3, relu=True, math=math, bits=sv.a1_bits,
+                   bits_mode=1 if sv.a1_bits is not None else 0)
     K.conv_forward(Sl(a1), packs.get("temporal_aggregator.attention.2.weight", False, F),
                    P["temporal_aggregator.attention.2.bias"], Sl(a2), 3, relu=True, math=math)
     K.conv_forward(Sl(a2), packs.get("temporal_aggregator.attention.4.weight", False, F),
@@ -454,8 +467,11 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                    mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
     da1 = _new(dev, B, H, W, F, dtype=act_dtype)
-    K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3,
-                   mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
+    if sv.a1_bits is not None:
+        K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3, math=math, bits=sv.a1_bits, bits_mode=2)
+    else:
+        K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3,
+                       mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
     _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
     K.conv_forward(Sl(da1), packs.get(pre + "0.weight", True, F, T * F), None, Sl(daligned), 3,
                    accumulate=True, math=math)
@@ -486,7 +502,9 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             cin_store = dy_t.shape[-1]
             wp = packs.get(name + "weight", True, cin_store, chans[li])
             dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else x_t.dtype)
-            if li > 0:
+            if li > 0 and sv.flow_bits[li] is not None:
+                K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, math=math, bits=sv.flow_bits[li], bits_mode=2)
+            elif li > 0:
                 K.conv_forward(Sl(dy_t), wp, None, Sl(dx_t, chans[li]), 3, mask=Sl(x_t), mask_c0=0,
                                mask_c1=chans[li], math=math)
             else:

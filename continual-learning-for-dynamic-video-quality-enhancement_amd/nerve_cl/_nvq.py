@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
         ("math", ci),
         ("in_bf16", ci), ("out_bf16", ci), ("out2_bf16", ci), ("res_bf16", ci), ("mask_bf16", ci),
         ("bits", vp), ("bits_mode", ci), ("center_cin", ci), ("in_plane", C.c_uint),
-        ("tile_rows", ci),
+        ("tile_rows", ci), ("bits_words", ci),
     ]
 
 
@@ -422,7 +422,7 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
                  mask_c1: int = 0, math: int = MATH_F32, alg_cin: Optional[int] = None,
                  bits: Optional[torch.Tensor] = None, bits_mode: int = 0, center_cin: int = 0,
                  tile_rows: int = 0) -> ConvDesc:
-    """bits: int32 [N,H,W] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask.
+    """bits: int32 [N,H,W] or [N,H,W,words] one-bit ReLU masks (see nvq_conv_desc): bits_mode 1 = write, 2 = read as the mask.
     center_cin: leading input channels whose weights are zero outside the centre tap (a hint, see nvq_conv_desc)."""
     n, h, w, _ = x.t.shape
     assert out.t.shape[:3] == x.t.shape[:3]
@@ -445,8 +445,9 @@ def _conv_desc(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: Sl
     d.res_bf16 = res.bf16 if res is not None else 0
     d.mask_bf16 = mask.bf16 if mask is not None else 0
     if bits_mode:
-        assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape) == (n, h, w) and bits.is_contiguous()
+        assert bits is not None and bits.dtype == torch.int32 and tuple(bits.shape[:3]) == (n, h, w) and bits.is_contiguous()
         d.bits, d.bits_mode = ptr(bits), bits_mode
+        d.bits_words = bits.shape[3] if bits.dim() == 4 else 1        # [N,H,W] (cout <= 32) or [N,H,W,ceil(cout / 32)]
     d.center_cin = center_cin
     d.in_plane = x.plane
     d.tile_rows = tile_rows
@@ -470,7 +471,7 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
         esz = lambda sl: 2.0 if sl.bf16 else 4.0   # noqa: E731  bytes per element
         nbytes = cin * esz(x) + out.c * esz(out) * (2 if accumulate else 1) \
             + (res.c * esz(res) if res is not None else 0) + (out2.c * esz(out2) if out2 is not None else 0) \
-            + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0) + (4 if bits_mode else 0)
+            + ((mask_c1 - mask_c0) * esz(mask) if mask is not None else 0) + (4 * (bits.shape[3] if bits is not None and bits.dim() == 4 else 1) if bits_mode else 0)
         TIMER.stop(ev0, f"conv_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{_nt(out.c) // 16},{ksize}>", 2.0 * n * h * w * (cin * ksize * ksize - center_cin * (ksize * ksize - 1)) * out.c,
                    n * h * w * nbytes, f"n{n} cin{x.c}{'h' if x.bf16 else ''} cout{out.c}{'h' if out.bf16 else ''}"
                    + (" acc" if accumulate else "")

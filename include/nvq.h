@@ -90,10 +90,11 @@ typedef struct nvq_conv_desc {
      * pointer, although typed float*, addresses bf16 data).  bf16 tensors need NVQ_MATH_BF16, a bf16 input
      * needs cin, in_ld, in_coff % 8 == 0, and every slice must be 8-byte addressable. */
     int in_bf16, out_bf16, out2_bf16, res_bf16, mask_bf16;
-    /* One-bit ReLU masks (NVQ_MATH_BF16, cout <= 32, vector epilogue): bits[(n*h + y)*w + x] holds bit c = "output
-     * channel c of this pixel is > 0".  bits_mode 1: written from the value stored to `out` (the dense layer's forward);
-     * bits_mode 2: read as the mask of channels [0, cout_store) instead of a `mask` tensor (its mirror-form gradient
-     * conv: 4 bytes per pixel instead of 64); 0: unused. */
+    /* One-bit ReLU masks (NVQ_MATH_BF16, vector epilogue; cout <= 32, or a 3x3 conv of a bf16 input with more output channels):
+     * word c / 32 of the bits_words (0 = 1) words of pixel (n*h + y)*w + x holds bit c % 32 = "output channel c of this pixel
+     * is > 0".  bits_mode 1: written from the value stored to `out` (a conv + ReLU forward); bits_mode 2: read as the mask of
+     * channels [0, cout_store) instead of a `mask` tensor (the input-gradient conv of the layer behind it: 4 bytes per pixel
+     * and 32 channels instead of 64); 0: unused. */
     unsigned* bits;
     int bits_mode;
     /* 3x3 only, a hint: the packed weights of input channels [0, center_cin) are zero outside the centre tap (the
@@ -111,6 +112,8 @@ typedef struct nvq_conv_desc {
      * 8x32-pixel, four-wave form (the automatic choice for bf16 input is the eight-wave form: 16x32 tiles for cout <= 32,
      * two 32-channel halves per workgroup for cout >= 64).  Lets a caller A/B the two forms without any library state. */
     int tile_rows;
+    /* words per pixel of `bits` (0 or 1: one word, cout <= 32) */
+    int bits_words;
 } nvq_conv_desc;
 /* epilogue: v = acc + bias; if relu v = max(v,0); v *= alpha; out2 = v;
  *           if c < res_cmax v += res; if accumulate v += out; if mask<=0 on [c0,c1) v = 0; out = v */

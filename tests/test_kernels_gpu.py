@@ -1249,6 +1249,38 @@ def test_conv_bf16_one_bit_relu_masks(K, N, H, W):
     assert torch.equal(out_mask, out_bits)
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(96, 128, 1, 20, 37), (128, 64, 2, 9, 33), (192, 64, 1, 17, 40)])
+def test_conv_bf16_one_bit_relu_masks_of_wide_layers(K, cin, cout, N, H, W):
+    """The same with more than 32 output channels (the flow net's and the attention's hidden layers): cout / 32 words per pixel,
+    written by the channel-split 3x3 kernel's two halves (and its channel chunks) and read back by the input-gradient conv
+    of the layer behind, whose own output is that wide."""
+    nw = cout // 32
+    x = to_nhwc_bf16(bf(rnd(N, cin, H, W)))
+    w, b = rnd(cout, cin, 3, 3, scale=0.1), rnd(cout)
+    y = torch.zeros(N, H, W, cout, device="cuda", dtype=torch.bfloat16)
+    bits = torch.zeros(N, H, W, nw, dtype=torch.int32, device="cuda")
+    K.conv_forward(K.Sl(x), K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16), b.cuda(), K.Sl(y), 3, relu=True, math=K.MATH_BF16,
+                   bits=bits, bits_mode=1)
+    y_plain = torch.zeros_like(y)
+    K.conv_forward(K.Sl(x), K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16), b.cuda(), K.Sl(y_plain), 3, relu=True,
+                   math=K.MATH_BF16)
+    assert torch.equal(y, y_plain)
+    act = (y.float() > 0).to(torch.int64).view(N, H, W, nw, 32)
+    want = (act << torch.arange(32, device="cuda")).sum(-1)
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, want)
+    # the input gradient of a following 3x3 conv (cout -> 32), masked by this layer's ReLU: bits vs the activation tensor
+    dy = to_nhwc_bf16(bf(rnd(N, 32, H, W, seed=4)))
+    wt = K.conv_pack(rnd(32, cout, 3, 3, scale=0.1, seed=5).cuda(), True, 32, cout, math=K.MATH_BF16)
+    out_mask = torch.empty(N, H, W, cout, device="cuda", dtype=torch.bfloat16)
+    out_bits = torch.empty_like(out_mask)
+    K.conv_forward(K.Sl(dy), wt, None, K.Sl(out_mask), 3, mask=K.Sl(y), mask_c0=0, mask_c1=cout, math=K.MATH_BF16)
+    K.conv_forward(K.Sl(dy), wt, None, K.Sl(out_bits), 3, math=K.MATH_BF16, bits=bits, bits_mode=2)
+    assert torch.equal(out_mask, out_bits)
+    with pytest.raises(RuntimeError, match="bit masks"):      # the four-wave 64-channel kernel has no bit path
+        K.conv_forward(K.Sl(x), K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16), b.cuda(), K.Sl(y), 3, relu=True,
+                       math=K.MATH_BF16, bits=bits, bits_mode=1, tile_rows=8)
+
+
 def test_dwconv_bf16_with_fused_batchnorm_input(K):
     """bn=(mean, invstd, gamma, beta, group_images): the depthwise kernels consume relu(bn(x)) evaluated while staging x;
     must equal bn_apply_relu (bf16 output) followed by the plain kernels, bit for bit."""
