@@ -497,6 +497,182 @@ __global__ __launch_bounds__(M_T) void corr_bwd_mfma_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- gradient w.r.t. x1 (WHICH == 1), strip form (bf16 tensors)
+// As corr_fwd_strip_kernel: a workgroup walks down a column block; the 16 halo rows of `other` (the centre features) are a
+// ring in LDS of which a tile fetches only the 8 new rows, and they and the tile's dcorr rows are fetched into registers under
+// the MFMAs of the tile before.  (The tile form stages 16 x 24 halo pixels and 8 x 16 dcorr rows per 128 pixels and does nothing
+// else meanwhile.)
+template <int C>
+__global__ __launch_bounds__(M_T) void corr_bwd1_strip_kernel(const __bf16* __restrict__ dcorr, int dcorr_ld,
+                                                              const __bf16* __restrict__ other, int other_ld, int other_images,
+                                                              int H, int W, int tilesX, int tilesY, int njobs,
+                                                              float* __restrict__ dx, int dx_ld, int dx_coff, int accumulate,
+                                                              __bf16* __restrict__ dx16, int dx16_ld, const nvq_corr_addends ad) {
+    constexpr int YS = C + 8;
+    constexpr int NCB = C / 16;
+    constexpr int PPP = C / 8;
+    constexpr int HITEMS = 8 * MHW * PPP;        // pieces of 8 halo rows
+    constexpr int HPER = (HITEMS + M_T - 1) / M_T;
+    constexpr int DITEMS = MT_H * MT_W * 12;     // pieces of the tile's dcorr rows (channels 0..95)
+    constexpr int DPER = (DITEMS + M_T - 1) / M_T;
+    __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
+    __shared__ __attribute__((aligned(16))) __bf16 ds[MT_H * MT_W * M_DSTR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, r = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int seg_rows = (tilesY + MS_SEG - 1) / MS_SEG;
+    const float inv = 1.f / (float)C;
+
+    m_u32x4 hv[HPER], dv[DPER];
+    unsigned hokm = 0, dokm = 0;
+    auto fetch_rows = [&](int n2, int ty, int tx, int half) {
+        hokm = 0;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int k = 0; k < HPER; ++k) {
+            const int item = tid_o + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hyl = hp / MHW, hx = hp - hyl * MHW;
+            const int gy = ty * MT_H + 8 * half + hyl - MD, gx = tx * MT_W + hx - MD;
+            const bool ok = item < HITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hokm |= (ok ? 1u : 0u) << k;
+            hv[k] = *reinterpret_cast<const m_u32x4*>(other + (ok ? ((size_t)(n2 * H + gy) * W + gx) * other_ld + 8 * q : 0));
+        }
+    };
+    auto commit_rows = [&](int ty, int half) {
+#pragma unroll
+        for (int k = 0; k < HPER; ++k) {
+            const int item = tid + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hyl = hp / MHW, hx = hp - hyl * MHW;
+            const int slot = (8 * half + hyl + 8 * (ty & 1)) & 15;
+            if (item < HITEMS)
+                *reinterpret_cast<m_u32x4*>(ys + (slot * MHW + hx) * YS + 8 * q) = (hokm >> k) & 1 ? hv[k] : (m_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto fetch_d = [&](int n, int ty, int tx) {
+        dokm = 0;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            const int item = tid_o + k * M_T;
+            const int dp = item / 12, q = item - dp * 12;
+            const int gy = ty * MT_H + dp / MT_W, gx = tx * MT_W + dp % MT_W;
+            const bool ok = item < DITEMS && gy < H && gx < W;
+            dokm |= (ok ? 1u : 0u) << k;
+            dv[k] = *reinterpret_cast<const m_u32x4*>(dcorr + (ok ? ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q : 0));
+        }
+    };
+    auto commit_d = [&]() {
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            const int item = tid + k * M_T;
+            const int dp = item / 12, q = item - dp * 12;
+            if (item < DITEMS)
+                *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = (dokm >> k) & 1 ? dv[k] : (m_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    typedef m_s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+    const int trq = p >> 2, trp = p & 3;                     // tr-read role inside the 16-lane group
+    const int gq = g < 3 ? g : 2;                            // halo columns 24..31 do not exist; their B rows are zero
+    const unsigned short* dsu = reinterpret_cast<const unsigned short*>(ds);
+
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+        int jt = job;
+        const int seg = jt % MS_SEG; jt /= MS_SEG;
+        const int tx = jt % tilesX;
+        const int n = jt / tilesX;
+        const int n2 = n % other_images;
+        const int ty0 = seg * seg_rows, ty1 = min(ty0 + seg_rows, tilesY);
+        if (ty0 >= ty1) continue;                             // (uniform)
+        __syncthreads();                                      // the previous job's last reads of ys / ds
+        fetch_rows(n2, ty0, tx, 0);
+        commit_rows(ty0, 0);
+        fetch_rows(n2, ty0, tx, 1);
+        fetch_d(n, ty0, tx);
+        for (int ty = ty0; ty < ty1; ++ty) {
+            commit_rows(ty, 1);
+            commit_d();
+            __syncthreads();                                  // the tile's halo ring and dcorr rows are in LDS
+            if (ty + 1 < ty1) { fetch_rows(n2, ty + 1, tx, 1); fetch_d(n, ty + 1, tx); }
+            const int rot = 8 * (ty & 1);
+            f32x4 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int i = 0; i < MN; ++i) {
+                // B: n = pixel p, k = halo column q' = 8g + t: dcorr[p, i*9 + (q' - p)] inside the band
+                unsigned bw[4];
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    unsigned half[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 8 * g + 2 * t2 + h;
+                        const int j = q - p;
+                        const bool band = j >= 0 && j <= 8;
+                        const unsigned v = dsu[(r * MT_W + p) * M_DSTR + i * MN + (band ? j : 0)];
+                        half[h] = band ? v : 0u;
+                    }
+                    bw[t2] = half[0] | (half[1] << 16);
+                }
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, (m_u32x4){bw[0], bw[1], bw[2], bw[3]});
+                const __bf16* yrow = ys + ((((r + i) + rot) & 15) * MHW + 8 * gq + trq) * YS + 4 * trp;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const m_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + cb * 16));
+                    const m_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + 4 * YS + cb * 16));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfrag, acc[cb], 0, 0, 0);
+                }
+            }
+            // D[m = channel cb*16 + 4g + e][n = pixel p]: the epilogue of the tile form
+            const int gy = ty * MT_H + r, gx = tx * MT_W + p;
+            if (gy < H && gx < W) {
+                const size_t apix = (size_t)(n * H + gy) * W + gx;
+                float* op = dx + apix * dx_ld + dx_coff + 4 * g;
+                float4 old[NCB];
+                if (accumulate) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) old[cb] = ld4(op + cb * 16);
+                }
+                typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+                u2_t ra[NCB], rb[NCB];
+                if (ad.a) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        ra[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.a) + apix * ad.a_ld + ad.a_coff + cb * 16 + 4 * g);
+                }
+                if (ad.b) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        rb[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.b) + apix * ad.b_ld + ad.b_coff + cb * 16 + 4 * g);
+                }
+                auto add_raw = [](float4& v, u2_t w) {
+                    v.x += __uint_as_float(w[0] << 16); v.y += __uint_as_float(w[0] & 0xffff0000u);
+                    v.z += __uint_as_float(w[1] << 16); v.w += __uint_as_float(w[1] & 0xffff0000u);
+                };
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
+                    if (accumulate) { v.x += old[cb].x; v.y += old[cb].y; v.z += old[cb].z; v.w += old[cb].w; }
+                    if (ad.a) add_raw(v, ra[cb]);
+                    if (ad.b) add_raw(v, rb[cb]);
+                    if (dx16)
+                        *reinterpret_cast<bf16x4*>(dx16 + apix * dx16_ld + cb * 16 + 4 * g) =
+                            (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                    else
+                        st4(op + cb * 16, v);
+                }
+            }
+            __syncthreads();                                  // everyone is done with the rows / dcorr the next commit replaces
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side (called from motion.hip's entry points)
 bool corr_mfma_supported(int C) { return C == 32 || C == 64; }
 
@@ -536,6 +712,16 @@ int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf
     NVQ_REQUIRE(dcorr_ld >= 96 && dcorr_ld % (dcorr_bf16 ? 8 : 4) == 0,
                 "correlation_backward(bf16): dcorr must be readable up to channel 96 (ld %d)", dcorr_ld);
     const int tilesX = (W + MT_W - 1) / MT_W, tilesY = (H + MT_H - 1) / MT_H;
+    if (which == 1 && dcorr_bf16 && other_bf16 && dcorr_ld % 8 == 0) {          // all-bf16 tensors: the strip form
+        const int njobs = N * tilesX * MS_SEG;
+        const int nwg = njobs < MS_MAXWG ? njobs : MS_MAXWG;
+#define NVQ_CB1(CC) hipLaunchKernelGGL(corr_bwd1_strip_kernel<CC>, dim3(nwg), dim3(M_T), 0, s, reinterpret_cast<const __bf16*>(dcorr), \
+                                       dcorr_ld, reinterpret_cast<const __bf16*>(other), other_ld, other_images, H, W, tilesX, tilesY, \
+                                       njobs, dx, dx_ld, dx_coff, accumulate, reinterpret_cast<__bf16*>(dx16), dx16_ld, ad)
+        if (C == 64) NVQ_CB1(64); else NVQ_CB1(32);
+#undef NVQ_CB1
+        return check_launch("correlation_backward(bf16, strip)");
+    }
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \
     hipLaunchKernelGGL((corr_bwd_mfma_kernel<CC, WH, DB>), grid, dim3(M_T), 0, s, dcorr, dcorr_ld, other, other_ld, other_images, H, W, tilesX, tilesY, dx, dx_ld, dx_coff, accumulate, other_bf16, groups, N, reinterpret_cast<__bf16*>(dx16), dx16_ld, ad)

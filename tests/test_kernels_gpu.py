@@ -992,6 +992,28 @@ def test_correlation_forward_strip_kernel(K, C, B, R, H, W, store_bf16):
     assert got[..., 81:].float().abs().max().item() == 0
 
 
+@pytest.mark.parametrize("C,B,R,H,W", [(64, 1, 2, 70, 20), (32, 2, 1, 45, 37), (64, 1, 1, 8, 16), (64, 1, 1, 131, 9)])
+@pytest.mark.parametrize("mode", ["overwrite", "accumulate", "bf16 out + addend"])
+def test_correlation_x1_gradient_strip_kernel(K, C, B, R, H, W, mode):
+    """All-bf16 tensors take the strip form of the x1 gradient (ring of halo rows, prefetched dcorr rows); against the tile form
+    on the same values with `other` stored as fp32 (same operands, same MFMA order: equal), in every epilogue mode."""
+    N = B * R
+    oth = bf(rnd(B, C, H, W, seed=3))
+    dcorr = to_nhwc_bf16(bf(rnd(N, 81, H, W, seed=5)), 96)
+    outs = []
+    for other in (to_nhwc_bf16(oth), to_nhwc(oth)):            # strip form / tile form
+        dx = to_nhwc(rnd(N, C, H, W, seed=7))
+        if mode == "bf16 out + addend":
+            o16 = torch.zeros(N, H, W, C, device="cuda", dtype=torch.bfloat16)
+            ta = to_nhwc_bf16(bf(rnd(N, 2 * C, H, W, seed=12)))
+            K.correlation_backward(1, dcorr, K.Sl(other), K.Sl(dx), False, math=K.MATH_BF16, out16=o16, addends=(K.Sl(ta, C, C),))
+            outs.append(o16)
+        else:
+            K.correlation_backward(1, dcorr, K.Sl(other), K.Sl(dx), mode == "accumulate", math=K.MATH_BF16)
+            outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("Fc,N,H,W", [(64, 2, 19, 37), (64, 1, 16, 32), (32, 2, 9, 20)])
 def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
     """nvq_conv_desc::in_plane / nvq_wgrad_desc::x_plane: the dense-block buffer as compact tensors [x | y_0 | ..] in one
