@@ -673,6 +673,176 @@ __global__ __launch_bounds__(M_T) void corr_bwd1_strip_kernel(const __bf16* __re
     }
 }
 
+// ---------------------------------------------------------------- gradient w.r.t. x2 (WHICH == 2), prefetching form (bf16)
+// The tile form stages 123 KB per (tile, frame group) - the halo of `other` AND of dcorr - with one workgroup per CU and
+// nothing in flight meanwhile.  Same tiles, same arithmetic and order here, but a persistent workgroup walks (tile, group)
+// steps and fetches the next step's two halos into registers under the current step's MFMAs.  (A ring of halo rows as in
+// the strip kernels would need one ring per frame group: 270 KB of LDS.)
+template <int C>
+__global__ __launch_bounds__(M_T) void corr_bwd2_pf_kernel(const __bf16* __restrict__ dcorr, int dcorr_ld,
+                                                           const __bf16* __restrict__ other, int other_ld, int other_images,
+                                                           int H, int W, int tilesX, int tilesY, int ntiles,
+                                                           float* __restrict__ dx, int dx_ld, int dx_coff, int accumulate,
+                                                           int groups, int group_images, __bf16* __restrict__ dx16, int dx16_ld,
+                                                           const nvq_corr_addends ad) {
+    constexpr int YS = C + 16;
+    constexpr int NCB = C / 16;
+    constexpr int PPP = C / 8;
+    constexpr int YITEMS = MHP * PPP, YPER = YITEMS / M_T;   // exact: 384 * {4, 8} / 512
+    constexpr int DITEMS = MHP * 12, DPER = DITEMS / M_T;    // exact: 4608 / 512 = 9
+    static_assert(YITEMS % M_T == 0 && DITEMS % M_T == 0, "halo pieces divide evenly");
+    __shared__ __attribute__((aligned(16))) __bf16 ys[MHP * YS];
+    __shared__ __attribute__((aligned(16))) __bf16 ds[MHP * M_DSTR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, r = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const float inv = 1.f / (float)C;
+
+    m_u32x4 yv[YPER], dv[DPER];
+    unsigned yokm = 0, dokm = 0;
+    auto locate = [&](int tile, int& n0, int& ty, int& tx) {
+        int bt = xcd_tile(tile, ntiles);
+        tx = bt % tilesX; bt /= tilesX;
+        ty = bt % tilesY;
+        n0 = bt / tilesY;
+    };
+    // both halos of image n (origin (ty*8 - 4, tx*16 - 4)) -> registers (clamped addresses; masked at commit)
+    auto fetch = [&](int n, int ty, int tx) {
+        yokm = 0; dokm = 0;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int n2 = n % other_images;
+#pragma unroll
+        for (int k = 0; k < YPER; ++k) {
+            const int item = tid_o + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            const int hy = hp / MHW, hx = hp - hy * MHW;
+            const int gy = ty * MT_H + hy - MD, gx = tx * MT_W + hx - MD;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            yokm |= (ok ? 1u : 0u) << k;
+            yv[k] = *reinterpret_cast<const m_u32x4*>(other + (ok ? ((size_t)(n2 * H + gy) * W + gx) * other_ld + 8 * q : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            const int item = tid_o + k * M_T;
+            const int dp = item / 12, q = item - dp * 12;
+            const int gy = ty * MT_H + dp / MHW - MD, gx = tx * MT_W + dp % MHW - MD;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            dokm |= (ok ? 1u : 0u) << k;
+            dv[k] = *reinterpret_cast<const m_u32x4*>(dcorr + (ok ? ((size_t)(n * H + gy) * W + gx) * dcorr_ld + 8 * q : 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < YPER; ++k) {
+            const int item = tid + k * M_T;
+            const int hp = item / PPP, q = item - hp * PPP;
+            *reinterpret_cast<m_u32x4*>(ys + hp * YS + 8 * q) = (yokm >> k) & 1 ? yv[k] : (m_u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            const int item = tid + k * M_T;
+            const int dp = item / 12, q = item - dp * 12;
+            *reinterpret_cast<m_u32x4*>(ds + dp * M_DSTR + 8 * q) = (dokm >> k) & 1 ? dv[k] : (m_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    typedef m_s16x4 __attribute__((address_space(3))) * lds_tr_ptr;
+    const int trq = p >> 2, trp = p & 3;
+    const int gq = g < 3 ? g : 2;
+    const unsigned short* dsu = reinterpret_cast<const unsigned short*>(ds);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { int n0, ty, tx; locate(tile, n0, ty, tx); fetch(n0, ty, tx); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        int n0, ty, tx;
+        locate(tile, n0, ty, tx);
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int gi = 0; gi < groups; ++gi) {
+            __syncthreads();                                  // everyone is done reading the previous step's tiles
+            commit();
+            __syncthreads();
+            // the next step's halos: the next frame group of this tile, or the first group of the workgroup's next tile
+            if (gi + 1 < groups) {
+                fetch(n0 + (gi + 1) * group_images, ty, tx);
+            } else if (tile + (int)gridDim.x < ntiles) {
+                int n1, ty1, tx1;
+                locate(tile + gridDim.x, n1, ty1, tx1);
+                fetch(n1, ty1, tx1);
+            }
+#pragma unroll 1
+            for (int i = 0; i < MN; ++i) {
+                // B: n = pixel p, k = halo column q' = 8g + t: dcorr[(r + i, q'), (8 - i)*9 + 8 - (q' - p)] inside the band
+                unsigned bw[4];
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    unsigned half[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 8 * g + 2 * t2 + h;
+                        const int j = q - p;
+                        const bool band = j >= 0 && j <= 8;
+                        const unsigned v = dsu[((r + i) * MHW + (band ? q : 0)) * M_DSTR + (8 - i) * MN + (band ? 8 - j : 0)];
+                        half[h] = band ? v : 0u;
+                    }
+                    bw[t2] = half[0] | (half[1] << 16);
+                }
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, (m_u32x4){bw[0], bw[1], bw[2], bw[3]});
+                const __bf16* yrow = ys + ((r + i) * MHW + 8 * gq + trq) * YS + 4 * trp;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const m_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + cb * 16));
+                    const m_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(yrow + 4 * YS + cb * 16));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfrag, acc[cb], 0, 0, 0);
+                }
+            }
+        }
+        // D[m = channel cb*16 + 4g + e][n = pixel p]: the epilogue of the tile form
+        const int gy = ty * MT_H + r, gx = tx * MT_W + p;
+        if (gy < H && gx < W) {
+            const size_t apix = (size_t)(n0 * H + gy) * W + gx;
+            float* op = dx + apix * dx_ld + dx_coff + 4 * g;
+            float4 old[NCB];
+            if (accumulate) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) old[cb] = ld4(op + cb * 16);
+            }
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            u2_t ra[NCB], rb[NCB];
+            if (ad.a) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    ra[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.a) + apix * ad.a_ld + ad.a_coff + cb * 16 + 4 * g);
+            }
+            if (ad.b) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    rb[cb] = *reinterpret_cast<const u2_t*>(reinterpret_cast<const __bf16*>(ad.b) + apix * ad.b_ld + ad.b_coff + cb * 16 + 4 * g);
+            }
+            auto add_raw = [](float4& v, u2_t w) {
+                v.x += __uint_as_float(w[0] << 16); v.y += __uint_as_float(w[0] & 0xffff0000u);
+                v.z += __uint_as_float(w[1] << 16); v.w += __uint_as_float(w[1] & 0xffff0000u);
+            };
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float4 v = make_float4(acc[cb][0] * inv, acc[cb][1] * inv, acc[cb][2] * inv, acc[cb][3] * inv);
+                if (accumulate) { v.x += old[cb].x; v.y += old[cb].y; v.z += old[cb].z; v.w += old[cb].w; }
+                if (ad.a) add_raw(v, ra[cb]);
+                if (ad.b) add_raw(v, rb[cb]);
+                if (dx16)
+                    *reinterpret_cast<bf16x4*>(dx16 + apix * dx16_ld + cb * 16 + 4 * g) =
+                        (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                else
+                    st4(op + cb * 16, v);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side (called from motion.hip's entry points)
 bool corr_mfma_supported(int C) { return C == 32 || C == 64; }
 
@@ -721,6 +891,17 @@ int corr_backward_mfma(int which, const float* dcorr, int dcorr_ld, int dcorr_bf
         if (C == 64) NVQ_CB1(64); else NVQ_CB1(32);
 #undef NVQ_CB1
         return check_launch("correlation_backward(bf16, strip)");
+    }
+    if (which == 2 && dcorr_bf16 && other_bf16 && dcorr_ld % 8 == 0) {          // all-bf16 tensors: the prefetching form
+        const int ntiles = tilesX * tilesY * N;
+        int nwg = ntiles < 256 ? ntiles : 256;                // one workgroup per CU (135 KB of LDS)
+        if (nwg >= 8) nwg &= ~7;                              // multiple of the XCD count, see xcd_tile()
+#define NVQ_CB2P(CC) hipLaunchKernelGGL(corr_bwd2_pf_kernel<CC>, dim3(nwg), dim3(M_T), 0, s, reinterpret_cast<const __bf16*>(dcorr), \
+                                        dcorr_ld, reinterpret_cast<const __bf16*>(other), other_ld, other_images, H, W, tilesX, tilesY, \
+                                        ntiles, dx, dx_ld, dx_coff, accumulate, groups, N, reinterpret_cast<__bf16*>(dx16), dx16_ld, ad)
+        if (C == 64) NVQ_CB2P(64); else NVQ_CB2P(32);
+#undef NVQ_CB2P
+        return check_launch("correlation_backward(bf16, prefetching)");
     }
     const dim3 grid((unsigned)((long)tilesX * tilesY * N));
 #define NVQ_CB(CC, WH, DB) \

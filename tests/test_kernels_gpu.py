@@ -1014,6 +1014,30 @@ def test_correlation_x1_gradient_strip_kernel(K, C, B, R, H, W, mode):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("C,B,R,H,W", [(64, 1, 2, 70, 20), (32, 2, 1, 45, 37), (64, 3, 2, 8, 16), (64, 40, 1, 9, 17)])
+@pytest.mark.parametrize("mode", ["overwrite", "accumulate", "bf16 out + addends"])
+def test_correlation_x2_gradient_prefetching_kernel(K, C, B, R, H, W, mode):
+    """All-bf16 tensors take the prefetching form of the x2 gradient (persistent workgroups over (tile, frame group) steps, the
+    next step's halos fetched under the MFMAs; more tiles than workgroups at B = 40); against the tile form on the same values
+    with `other` stored as fp32 (same operands, same order: equal), in every epilogue mode, one and two frame groups."""
+    N = B * R
+    oth = bf(rnd(N, C, H, W, seed=3))
+    dcorr = to_nhwc_bf16(bf(rnd(N, 81, H, W, seed=5)), 96)
+    outs = []
+    for other in (to_nhwc_bf16(oth), to_nhwc(oth)):            # prefetching form / tile form
+        dx = to_nhwc(rnd(B, C, H, W, seed=7))
+        if mode == "bf16 out + addends":
+            o16 = torch.zeros(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+            ta, tb = to_nhwc_bf16(bf(rnd(B, 2 * C, H, W, seed=12))), to_nhwc_bf16(bf(rnd(B, C, H, W, seed=13)))
+            K.correlation_backward(2, dcorr, K.Sl(other), K.Sl(dx), False, math=K.MATH_BF16, groups=R, out16=o16,
+                                   addends=(K.Sl(ta, C, C), K.Sl(tb)))
+            outs.append(o16)
+        else:
+            K.correlation_backward(2, dcorr, K.Sl(other), K.Sl(dx), mode == "accumulate", math=K.MATH_BF16, groups=R)
+            outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("Fc,N,H,W", [(64, 2, 19, 37), (64, 1, 16, 32), (32, 2, 9, 20)])
 def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
     """nvq_conv_desc::in_plane / nvq_wgrad_desc::x_plane: the dense-block buffer as compact tensors [x | y_0 | ..] in one
