@@ -35,6 +35,9 @@ import torch.nn.functional as F  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide); ridge = 2500 / 8 = 312 FLOP/B
+# algorithmic bytes of one train step per clip in bf16 storage (3 x the forward's 16 566 planes at cfg2)
+ALGO_GB_PER_CLIP_STEP = {"cfg2": 51.53, "cfg4 (SR part)": 16.66}
 
 
 def sources_sha() -> str:
@@ -367,6 +370,11 @@ def main():
             else:                       # bf16 MFMA on fp32-stored activations: HBM-bound
                 roofline = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": gbs / PEAK_HBM_GBS, "algorithmic_tflops": tflops, **common}
+                # the whole step against the layer-wise HBM bound of SURVEY.md 8(d): (algorithmic GB per clip and step x
+                # clips per second of pass A) / peak - tracks the headline, not one kernel
+                if tag in ALGO_GB_PER_CLIP_STEP and net.bf16_activations:
+                    roofline["whole_step_frac"] = ALGO_GB_PER_CLIP_STEP[tag] * value / PEAK_HBM_GBS
+                    roofline["whole_step_algorithmic_gb_per_clip"] = ALGO_GB_PER_CLIP_STEP[tag]
     if timer is not None and kernels:
         # the residual dense stack as a whole (north-star: >= 40 % of the HBM roofline): every conv / weight-gradient launch
         # of the 8 dense blocks, forward and backward, algorithmic bytes over measured time
@@ -380,11 +388,19 @@ def main():
                               "tflops": rdb["flops"] / (rdb["ms_total"] * 1e-3) / 1e12}
     if timer is not None and args.detail:
         rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms_total"])
-        print("%-24s %-34s %5s %9s %9s %9s" % ("kernel", "shape", "calls", "ms/step", "TFLOP/s", "alg GB/s"), file=sys.stderr)
-        for (label, shape), d in rows[:40]:
+        # `of bound`: the shape's fraction of ITS roofline - HBM (8 TB/s) when its arithmetic intensity is under the bf16
+        # ridge (312 FLOP/B; 20 FLOP/B with exact-fp32 MFMA operands), the MFMA peak above it
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if args.math == "bf16" else PEAK_F32_MFMA_TFLOPS
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        print("%-24s %-38s %5s %9s %9s %9s %7s %9s" % ("kernel", "shape", "calls", "ms/step", "TFLOP/s", "alg GB/s",
+                                                      "FLOP/B", "of bound"), file=sys.stderr)
+        for (label, shape), d in rows[:48]:
             sec = d["ms_total"] * 1e-3
-            print("%-24s %-34s %5d %9.3f %9.1f %9.0f" % (label, shape, d["launches"] // args.steps,
-                  d["ms_total"] / args.steps, d["flops"] / sec / 1e12, d["bytes"] / sec / 1e9), file=sys.stderr)
+            ai = d["flops"] / max(d["bytes"], 1)
+            frac = d["flops"] / sec / 1e12 / peak_tf if ai >= ridge else d["bytes"] / sec / 1e9 / PEAK_HBM_GBS
+            print("%-24s %-38s %5d %9.3f %9.1f %9.0f %7.0f %6.2f %s" % (
+                label, shape, d["launches"] // args.steps, d["ms_total"] / args.steps, d["flops"] / sec / 1e12,
+                d["bytes"] / sec / 1e9, ai, frac, "mfma" if ai >= ridge else "hbm"), file=sys.stderr)
     # "PSNR vs ref" (second half of BASELINE.json's metric): a crop of the benchmark batch through the benchmarked mode,
     # checked against the fp32 CPU oracle inside the cpu_baseline leg
     parity_probe = None
