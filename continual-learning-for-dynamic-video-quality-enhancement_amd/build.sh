@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function ${NVQ_EXTRA_FLAGS:-}"
 BUILD=build
 OUT=libnvq.so
 # NVQ_DEBUG_TOOLS=1: the diagnostic build for tools/ (nvq_debug_* entry points, tools/nvq_debug.h) as libnvq_debug.so; the

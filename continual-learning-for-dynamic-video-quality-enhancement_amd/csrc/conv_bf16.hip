@@ -24,28 +24,8 @@ void set_conv_debug_mode(int m) { g_debug_mode = m; }
 constexpr int g_debug_mode = 0;
 #endif
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece
-
-constexpr int KCB = 32;    // input channels per K chunk
 constexpr int XSB = 48;    // bf16 per staged pixel: 32 data + 16 pad (96 B: the 16 pixels x 4 k-groups of one
                            // ds_read_b128 / ds_read_b64_tr_b16 instruction land on distinct 16-B slots)
-
-// Per-(cz, kc) weight slab in the packed buffer / in LDS, padded so that 256 threads move it as a whole number
-// of 16-byte pieces each.
-__host__ __device__ constexpr int ws_stride_halfs(int taps, int NT) { return ((taps * 4 * NT * 8 + 2047) / 2048) * 2048; }
-
-__device__ __forceinline__ float4 as_f4(u32x4 v) {
-    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-}
-__device__ __forceinline__ bf16x4 cvt4(float4 v) {
-    return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-}
-__device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
-    return (bf16x8){(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
-}
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }          // even channel
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // odd channel
 
 // ---------------------------------------------------------------- weight packing (bf16)
 // wpack[cz][kc][tap][g][n][j] (g = 0..3, n = 0..NT-1, j = 0..7) = bf16(W[cout = cz*NT + n][ch = kc*32 + 8g + j][tap])
@@ -909,6 +889,12 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them.  (Choosing the 8-row
     // tiles of the 4-wave kernel for launches that leave the device under-filled gave 4.43 -> 4.23 ms on the 8-clip 64x64 step
     // and was taken out again: the small parity tests would no longer run the kernel the 540p benchmark runs.)
+    // the same tile on v_mfma_f32_32x32x16_bf16 (conv_m32.hip): tile_rows 162 = two rows per wave (8 waves), 164 = four rows
+    // per wave (4 waves).  Automatic for up to 128 input channels (profiles/r04_mfma32_per_shape.txt: the two-row form is 1 - 7 %
+    // faster there and 0 - 4 % slower on 160 / 192; the four-row form loses everywhere); tile_rows 16 = always the 16x16x32 form.
+    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && vec_ok &&
+        (d.tile_rows == 162 || d.tile_rows == 164 || (d.tile_rows == 0 && d.cin <= 128)))
+        return conv_forward_m32(d, d.tile_rows == 164 ? 4 : 2, g_debug_mode & 3, s);
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && d.tile_rows != 8) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
@@ -984,6 +970,7 @@ int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, in
 
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s) {
+    if ((d.variant & 15) != 1 && wgrad_m32_takes(d)) return conv_wgrad_m32(d, s);
     // nsplit / nci come from the caller in 32-ci units; with bf16 x and >= 64 input channels use 64-ci workgroups
     const bool wide = d.x_bf16 && d.dy_bf16 && d.cin_w >= 64;   // (the bf16-x / fp32-dy wide variant spills)
     const int ncig = wide ? (nci + 1) / 2 : nci;

@@ -8,7 +8,7 @@ constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
 constexpr int WGRAD_MAX_WG = 512;      // workgroups per wgrad launch (2 per CU)
-constexpr int WGRAD_MAX_SLABS = 1024;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds
+constexpr int WGRAD_MAX_SLABS = 1536;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds (256 x 6)
 
 static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
 
@@ -16,6 +16,28 @@ static inline int choose_nt(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 3
 void set_conv_debug_mode(int m);
 #endif
 void conv_occupancy_bf16(int* out);
+
+// ---- shared by the NVQ_MATH_BF16 kernels (conv_bf16.hip: v_mfma_f32_16x16x32_bf16; conv_m32.hip: v_mfma_f32_32x32x16_bf16)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte piece
+
+constexpr int KCB = 32;    // input channels per K chunk
+
+// Per-(cz, kc) weight slab in the packed buffer / in LDS, padded so that 256 threads move it as a whole number
+// of 16-byte pieces each.
+__host__ __device__ constexpr int ws_stride_halfs(int taps, int NT) { return ((taps * 4 * NT * 8 + 2047) / 2048) * 2048; }
+
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ bf16x4 cvt4(float4 v) {
+    return (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+__device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
+    return (bf16x8){(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }          // even channel
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // odd channel
 
 // NVQ_MATH_BF16 variants (conv_bf16.hip)
 size_t pack_floats_bf16(int cout, int cin_store, int ksize);
@@ -34,6 +56,12 @@ int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int t
 int upsampler_tail_bf16(const nvq_conv_desc& d, const float* frames, int T, int t_center, int Cimg, int s, float* out,
                         unsigned char* pass, hipStream_t st);
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s);
+// v_mfma_f32_32x32x16_bf16 kernels (conv_m32.hip)
+int conv_forward_m32(const nvq_conv_desc& d, int variant, int dbg, hipStream_t s);
+void conv_occupancy_m32(int* out);
+// all-input-channel 3x3 weight gradient (wgrad_m32.hip)
+bool wgrad_m32_takes(const nvq_wgrad_desc& d);
+int conv_wgrad_m32(const nvq_wgrad_desc& d, hipStream_t s);
 
 // Bias-gradient partials of the wgrad kernels: every thread holds the column sums of the dy pieces it staged
 // (channels 4*(tid&7)..+3 of its co chunk).  The 32 threads that share tid&7 are summed through LDS and the

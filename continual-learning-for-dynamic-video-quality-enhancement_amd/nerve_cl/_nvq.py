@@ -66,7 +66,7 @@ class WgradDesc(C.Structure):
         ("workspace", vp), ("workspace_bytes", sz),
         ("n", ci), ("h", ci), ("w", ci), ("ksize", ci),
         ("alpha", cf), ("accumulate", ci), ("math", ci),
-        ("x_bf16", ci), ("dy_bf16", ci), ("x_plane", C.c_uint),
+        ("x_bf16", ci), ("dy_bf16", ci), ("x_plane", C.c_uint), ("variant", ci),
     ]
 
 
@@ -514,7 +514,7 @@ def rdb_backward_weights(lff: torch.Tensor, ws: Sequence[torch.Tensor], F: int):
 
 def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torch.Tensor],
                ws: torch.Tensor, ksize: int, *, alpha: float = 1.0, accumulate: bool = False,
-               math: int = MATH_F32) -> None:
+               math: int = MATH_F32, variant: int = 0) -> None:
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
     d = WgradDesc()
@@ -525,6 +525,7 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.n, d.h, d.w, d.ksize = n, h, w, ksize
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
     d.x_bf16, d.dy_bf16, d.x_plane = x.bf16, dy.bf16, x.plane
+    d.variant = variant
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
         TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,

@@ -304,6 +304,8 @@ class EWC:
             o = torch.cat([ov[n].reshape(-1) for n in sg.names])
             term = _PenaltyFn.apply(None, self.ewc_lambda, o, f, *params)
             total = term if total is None else total + term
+        if total is None:                                      # no trainable parameter: si_lambda * 0.0 (reference ewc.py:370-379)
+            return torch.zeros((), device=next(self.model.parameters()).device)
         return total
 
     def penalty(self, model: Optional[nn.Module] = None):
@@ -434,7 +436,7 @@ class SynapticIntelligence:
                     continue
                 views_w, views_p = sg.views(W), sg.views(p_old)
                 for n, p in sg.named:                         # loose parameters / accumulated gradients: per tensor
-                    if p.grad is not None:
+                    if p.grad is not None and p.numel() > 0:
                         g = p.grad.detach().float().contiguous()
                         _nvq.si_update(p.detach().float().contiguous(), g, views_p[n].view(-1), views_w[n].view(-1))
 

@@ -16,8 +16,8 @@ import torch
 
 @dataclass
 class MemorySample:
-    """One stored sample as the reference exposes it (memory.py:16-34: ``memory.buffer`` is a list of these).  The store
-    below keeps plain dicts; ``EpisodicMemory.buffer`` hands them out in this form."""
+    """One stored sample as the reference exposes it (memory.py:16-34: ``memory.buffer`` is a list of these, and it is the
+    store itself: appending / removing samples or changing ``importance`` / ``access_count`` through it takes effect)."""
     frame_lr: torch.Tensor
     frame_hr: torch.Tensor
     metadata: Dict[str, Any] = field(default_factory=dict)
@@ -43,7 +43,7 @@ class EpisodicMemory:
         if strategy not in self.STRATEGIES:
             raise ValueError(f"unknown strategy {strategy!r}")
         self.capacity, self.strategy, self.diversity_weight = capacity, strategy, diversity_weight
-        self._items: List[dict] = []
+        self._items: List[MemorySample] = []
         self._seen = 0
         self._rng = random.Random(seed)
 
@@ -56,12 +56,16 @@ class EpisodicMemory:
 
     @property
     def buffer(self) -> List[MemorySample]:
-        """The stored samples in the reference's form (a read-only snapshot: tensors are shared, the list is new)."""
-        return [MemorySample(it["lr"], it["hr"], it["meta"], it["importance"], it["access_count"]) for it in self._items]
+        """The stored samples: the LIVE list, as in the reference (memory.py:52)."""
+        return self._items
+
+    @buffer.setter
+    def buffer(self, items: List[MemorySample]) -> None:
+        self._items = list(items)
 
     @staticmethod
-    def _ctype(item: dict) -> str:
-        return item["meta"].get("content_type", "unknown")
+    def _ctype(item: MemorySample) -> str:
+        return item.metadata.get("content_type", "unknown")
 
     def _by_type(self) -> Dict[str, List[int]]:
         groups: Dict[str, List[int]] = defaultdict(list)
@@ -79,8 +83,7 @@ class EpisodicMemory:
     def store(self, frame_lr: torch.Tensor, frame_hr: torch.Tensor, metadata: Optional[Dict[str, Any]] = None,
               importance: float = 1.0) -> bool:
         """Reference memory.py:84-130 (same argument names: the scripts pass them positionally, callers may use keywords)."""
-        item = {"lr": frame_lr.detach().cpu(), "hr": frame_hr.detach().cpu(), "meta": metadata or {},
-                "importance": float(importance), "access_count": 0}
+        item = MemorySample(frame_lr.detach().cpu(), frame_hr.detach().cpu(), metadata or {}, float(importance), 0)
         self._seen += 1
         if len(self._items) < self.capacity:
             self._items.append(item)
@@ -96,15 +99,15 @@ class EpisodicMemory:
                 return True
             return self._reservoir(item)
         if self.strategy == "importance":
-            j = min(range(len(self._items)), key=lambda k: self._items[k]["importance"])
-            if item["importance"] > self._items[j]["importance"]:
+            j = min(range(len(self._items)), key=lambda k: self._items[k].importance)
+            if item.importance > self._items[j].importance:
                 self._items[j] = item
                 return True
             return False
         if self.strategy == "diversity":
             # replace the stored sample closest in mean colour if the newcomer is further than 0.1 from it (reference :186-211)
-            feats = torch.stack([it["lr"].mean(dim=(1, 2)) for it in self._items])
-            dist = torch.norm(feats - item["lr"].mean(dim=(1, 2)), dim=1)
+            feats = torch.stack([it.frame_lr.mean(dim=(1, 2)) for it in self._items])
+            dist = torch.norm(feats - item.frame_lr.mean(dim=(1, 2)), dim=1)
             j = int(dist.argmin())
             if dist[j] > 0.1:
                 self._items[j] = item
@@ -135,12 +138,12 @@ class EpisodicMemory:
         else:
             idx = self._spread(batch_size)
         for i in idx:
-            self._items[i]["access_count"] += 1
-        lr = torch.stack([self._items[i]["lr"] for i in idx])
-        hr = torch.stack([self._items[i]["hr"] for i in idx])
+            self._items[i].access_count += 1
+        lr = torch.stack([self._items[i].frame_lr for i in idx])
+        hr = torch.stack([self._items[i].frame_hr for i in idx])
         if device is not None:
             lr, hr = lr.to(device), hr.to(device)
-        return lr, hr, [self._items[i]["meta"] for i in idx]
+        return lr, hr, [self._items[i].metadata for i in idx]
 
     def get_stats(self) -> Dict[str, Any]:
         return {"size": len(self), "capacity": self.capacity, "utilization": len(self) / self.capacity,
@@ -151,13 +154,12 @@ class EpisodicMemory:
         self._items, self._seen = [], 0
 
     def save(self, path: str) -> None:
-        torch.save({"buffer": [(it["lr"], it["hr"], it["meta"], it["importance"]) for it in self._items],
+        torch.save({"buffer": [(it.frame_lr, it.frame_hr, it.metadata, it.importance) for it in self._items],
                     "total_seen": self._seen, "strategy": self.strategy, "capacity": self.capacity}, path)
 
     def load(self, path: str) -> None:
         blob = torch.load(path, weights_only=True)
-        self._items = [{"lr": lr, "hr": hr, "meta": meta, "importance": float(imp), "access_count": 0}
-                       for lr, hr, meta, imp in blob["buffer"]]
+        self._items = [MemorySample(lr, hr, meta, float(imp), 0) for lr, hr, meta, imp in blob["buffer"]]
         self._seen = blob["total_seen"]
 
 
@@ -184,15 +186,15 @@ class StreamingEpisodicMemory(EpisodicMemory):
         if not self._items:
             raise ValueError("memory is empty")
         batch_size = min(batch_size, len(self._items))
-        w = [(1 - self.recency_weight) * it["importance"] + self.recency_weight / (1 + self.current_time - it["meta"]["_time"])
+        w = [(1 - self.recency_weight) * it.importance + self.recency_weight / (1 + self.current_time - it.metadata["_time"])
              for it in self._items]
         idx: List[int] = []
         pool = list(range(len(self._items)))
         for _ in range(batch_size):                           # weighted sampling without replacement
             j = self._rng.choices(range(len(pool)), weights=[w[i] for i in pool])[0]
             idx.append(pool.pop(j))
-        lr = torch.stack([self._items[i]["lr"] for i in idx])
-        hr = torch.stack([self._items[i]["hr"] for i in idx])
+        lr = torch.stack([self._items[i].frame_lr for i in idx])
+        hr = torch.stack([self._items[i].frame_hr for i in idx])
         if device is not None:
             lr, hr = lr.to(device), hr.to(device)
-        return lr, hr, [{k: v for k, v in self._items[i]["meta"].items() if k != "_time"} for i in idx]
+        return lr, hr, [{k: v for k, v in self._items[i].metadata.items() if k != "_time"} for i in idx]

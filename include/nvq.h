@@ -108,9 +108,12 @@ typedef struct nvq_conv_desc {
      * pixel row a layer writes shares its 128-byte line with the next pixel, not with another layer.  0 = the usual
      * interleaved buffer.  Outputs, residuals and masks are ordinary (ld, coff) slices of those tensors in either case. */
     unsigned in_plane;
-    /* Kernel-variant hint, results do not depend on it: 0 = automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their
-     * 8x32-pixel, four-wave form (the automatic choice for bf16 input is the eight-wave form: 16x32 tiles for cout <= 32,
-     * two 32-channel halves per workgroup for cout >= 64).  Lets a caller A/B the two forms without any library state. */
+    /* Kernel-variant hint, results do not depend on it (beyond the fp32 summation order inside a 32-channel K chunk): 0 =
+     * automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their 8x32-pixel, four-wave form (the automatic choice for bf16 input is
+     * an eight-wave form: 16x32 tiles for cout <= 32, two 32-channel halves per workgroup for cout >= 64); for cout <= 32 also
+     * 16 = the 16x32-tile kernel on v_mfma_f32_16x16x32_bf16, 162 / 164 = the same tile on v_mfma_f32_32x32x16_bf16 with two /
+     * four tile rows per wave (automatic: 162 up to 128 input channels, 16 above).  Lets a caller A/B the forms without any
+     * library state. */
     int tile_rows;
     /* words per pixel of `bits` (0 or 1: one word, cout <= 32) */
     int bits_words;
@@ -152,6 +155,10 @@ typedef struct nvq_wgrad_desc {
     float alpha; int accumulate; int math;
     int x_bf16, dy_bf16;                /* storage type of x / dy (see nvq_conv_desc); need NVQ_MATH_BF16 */
     unsigned x_plane;                   /* slice-planar x (see nvq_conv_desc::in_plane; bf16 x, x_coff == 0); 0 = interleaved */
+    /* Kernel-variant hint, results do not depend on it (up to the summation order): 0 = automatic; 1 = always the
+     * (pixel split, ci chunk, co chunk) kernels, never the all-input-channel kernel (3x3, cout = 32, slice-planar bf16 x,
+     * bf16 dy, cin in {64, .., 192}: x read without halo and dy once per launch).  Lets a caller A/B the two forms. */
+    int variant;
 } nvq_wgrad_desc;
 size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */
 int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);

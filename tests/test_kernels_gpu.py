@@ -688,6 +688,37 @@ def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     assert rel(db, dy.sum((0, 2, 3))) < TOL
 
 
+@pytest.mark.parametrize("Fc,cin,N,H,W", [(64, 64, 2, 16, 64), (64, 96, 1, 21, 45), (64, 128, 2, 9, 33), (64, 160, 3, 17, 70),
+                                            (64, 192, 1, 40, 96), (32, 64, 2, 8, 32), (32, 160, 1, 13, 50), (128, 192, 1, 12, 40),
+                                            (64, 192, 5, 37, 130)])
+def test_conv_bf16_weight_gradient_all_input_channels(K, Fc, cin, N, H, W):
+    """nvq_conv_wgrad on a slice-planar bf16 dense-block buffer, 3x3, cout = 32: the all-input-channel kernel (wgrad_m32.hip: x
+    units without halo, dy with halo, six MFMA waves + two dy waves, persistent over tiles) against autograd's weight / bias
+    gradient of F.conv2d on the same bf16 values, and against the (pixel split, ci chunk) kernel (variant = 1).  Sizes with
+    partial tiles in both directions, one to many tiles per workgroup, leading tensors of 32 / 64 / 128 channels, alpha and
+    accumulate."""
+    x, dy = bf(rnd(N, cin, H, W)), bf(rnd(N, 32, H, W, seed=3))
+    w = rnd(32, cin, 3, 3).requires_grad_()
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    cat = K.CatBuf("cuda", N, H, W, Fc, (cin - Fc) // 32 + 1, 256, torch.bfloat16, planar=True)
+    xn = to_nhwc_bf16(x)
+    cat.lead.copy_(xn[..., :Fc])
+    for j in range((cin - Fc) // 32):
+        cat.slices[j].copy_(xn[..., Fc + 32 * j:Fc + 32 * (j + 1)])
+    ds = to_nhwc_bf16(dy, 40, 8)
+    ws = ws_tensor(K)
+    outs = []
+    for variant in (0, 1):
+        dw, db = torch.full((32, cin, 3, 3), 7.0, device="cuda"), torch.full((32,), 7.0, device="cuda")
+        K.conv_wgrad(cat.inp(cin), cin, K.Sl(ds, 32, 8), dw, db, ws, 3, math=K.MATH_BF16, variant=variant)
+        outs.append((dw, db))
+    assert rel(outs[0][0], w.grad) < TOL and rel(outs[0][1], dy.sum((0, 2, 3))) < TOL
+    assert rel(outs[0][0], outs[1][0]) < TOL and rel(outs[0][1], outs[1][1]) < TOL
+    dw, db = outs[0][0].clone(), outs[0][1].clone()
+    K.conv_wgrad(cat.inp(cin), cin, K.Sl(ds, 32, 8), dw, db, ws, 3, alpha=0.5, accumulate=True, math=K.MATH_BF16)
+    assert rel(dw, 1.5 * w.grad) < TOL and rel(db, 1.5 * dy.sum((0, 2, 3))) < TOL
+
+
 def test_extractor_kernels_with_bf16_stored_tensors(K):
     """Depthwise conv and BatchNorm kernels reading / writing bf16-stored tensors (fp32 arithmetic inside)."""
     C, B, G, H, W = 32, 2, 3, 9, 14
@@ -1062,11 +1093,13 @@ def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
             K.conv_forward(buf.inp(cin), wp, b3.cuda(), buf.y(i), 3, relu=True, math=K.MATH_BF16, bits=bt, bits_mode=1)
         assert torch.equal(inter.t[..., cin:cin + 32], plan.slices[i]) and torch.equal(bits[0], bits[1])
         dws = []
-        for buf in (inter, plan):                            # weight gradient of the same layer: x = the prefix
+        for buf, variant in ((inter, 0), (plan, 1), (plan, 0)):   # weight gradient of the same layer: x = the prefix
             dw, db = torch.empty(32, cin, 3, 3, device="cuda"), torch.empty(32, device="cuda")
-            K.conv_wgrad(buf.inp(cin), cin, buf.y(4), dw, db, ws, 3, math=K.MATH_BF16)
+            K.conv_wgrad(buf.inp(cin), cin, buf.y(4), dw, db, ws, 3, math=K.MATH_BF16, variant=variant)
             dws.append((dw, db))
-        assert torch.equal(dws[0][0], dws[1][0]) and torch.equal(dws[0][1], dws[1][1])
+        assert torch.equal(dws[0][0], dws[1][0]) and torch.equal(dws[0][1], dws[1][1])   # the same kernel on either layout
+        # variant 0 on the slice-planar buffer is the all-input-channel kernel (wgrad_m32.hip): other fp32 summation order
+        assert rel(dws[2][0], dws[1][0]) < TOL and rel(dws[2][1], dws[1][1]) < TOL
     # 1x1 over all channels (lff) with residual x, 64-channel output into the next block's x; its weight gradient
     wl, bl = rnd(Fc, CAT, 1, 1, scale=0.1, seed=7), rnd(Fc, seed=8)
     wlp = K.conv_pack(wl.cuda(), False, CAT, math=K.MATH_BF16)
@@ -1215,16 +1248,71 @@ def test_conv_bf16_eight_wave_kernels_equal_the_four_wave_ones(K, cin, cout, ctr
     r16 = to_nhwc_bf16(bf(rnd(N, 64, H, W, seed=7)), 64) if res else None
     cs = (cout + 7) // 8 * 8
     outs = []
-    for rows in (0, 8):
+    for rows in (16, 8, 0):                                  # (16: the 16x16x32 eight-wave form whatever the automatic choice is)
         out = torch.full((N, H, W, cs), 3.0, device="cuda").bfloat16()
         K.conv_forward(K.Sl(xin, cin, 0), wp, bias, K.Sl(out, cout), 3, cout_store=cs, math=K.MATH_BF16, center_cin=ctr,
                        res=K.Sl(r16) if res else None, tile_rows=rows)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+    # the automatic choice may be the 32x32x16 form (cout <= 32, cin <= 128): other fp32 order inside a chunk, at most one
+    # bf16 ulp of the stored result
+    assert rel(outs[2].float(), outs[0].float()) < 8e-3
     ref = F.conv2d(x, bf(w), bias.cpu() if bias is not None else None, padding=1)
     if res:
         ref = ref + from_nhwc(r16.float())[:, :cout]
     assert rel(from_nhwc(outs[0][..., :cout].float()), ref) < 1.2e-2          # one bf16 rounding of the stored result
+
+
+@pytest.mark.parametrize("rows", [162, 164])
+@pytest.mark.parametrize("cin,ctr,N,H,W", [(64, 0, 2, 16, 32), (96, 64, 1, 35, 41), (160, 0, 2, 33, 70), (192, 64, 1, 50, 96),
+                                            (40, 0, 1, 19, 37)])
+def test_conv_bf16_dense_layer_on_32x32x16_mfma(K, rows, cin, ctr, N, H, W):
+    """conv_m32.hip: the cout <= 32 3x3 conv of a bf16 input on v_mfma_f32_32x32x16_bf16 (tile_rows 162: two tile rows per wave,
+    eight waves; 164: four rows per wave, four waves), every epilogue form the dense blocks and their mirror-form gradient convs
+    use - bias + ReLU + one-bit masks written, bit masks read with centre-tap-only leading channels, residual / second output /
+    accumulate / tensor mask with fp32 and bf16 outputs - against F.conv2d on the same bf16 values and against the 16x16x32
+    kernel (tile_rows 16); border and interior tiles, a cin that is not a multiple of 32."""
+    w, b = rnd(32, cin, 3, 3, scale=0.1), rnd(32, seed=2)
+    if ctr:
+        centre = w[:, :ctr, 1, 1].clone()
+        w[:, :ctr] = 0
+        w[:, :ctr, 1, 1] = centre
+    x = bf(rnd(N, cin, H, W, seed=5))
+    xin = to_nhwc_bf16(x, 256)
+    wp = K.conv_pack(w.cuda(), False, cin, math=K.MATH_BF16)
+    ref = F.conv2d(x, bf(w), b, padding=1)
+    # (a) forward form: bias + ReLU, bf16 output staged through LDS, bit masks written
+    res = {}
+    for r_ in (rows, 16):
+        out = torch.full((N, H, W, 40), 3.0, device="cuda").bfloat16()
+        bits = torch.zeros(N, H, W, dtype=torch.int32, device="cuda")
+        K.conv_forward(K.Sl(xin, cin, 0), wp, b.cuda(), K.Sl(out, 32, 8), 3, relu=True, math=K.MATH_BF16, bits=bits, bits_mode=1,
+                       center_cin=ctr, tile_rows=r_)
+        res[r_] = (out, bits)
+    out, bits = res[rows]
+    assert rel(from_nhwc(out[..., 8:].float()), F.relu(ref)) < 8e-3          # one bf16 rounding of the stored result
+    assert out[..., :8].float().abs().max().item() == 3.0                    # the neighbouring channels are untouched
+    want = ((out[..., 8:].float() > 0).to(torch.int64) << torch.arange(32, device="cuda")).sum(-1)
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, want)              # the bits describe the STORED values
+    assert rel(out.float(), res[16][0].float()) < 8e-3
+    # (b) gradient form: no bias, bit masks read, fp32 output (direct stores)
+    g32 = torch.full((N, H, W, 32), 5.0, device="cuda")
+    K.conv_forward(K.Sl(xin, cin, 0), wp, None, K.Sl(g32), 3, math=K.MATH_BF16, bits=bits, bits_mode=2, center_cin=ctr, tile_rows=rows)
+    refm = F.conv2d(x, bf(w), None, padding=1) * (from_nhwc(out[..., 8:].float()) > 0)
+    assert rel(from_nhwc(g32), refm) < TOL
+    # (c) alpha, residual, second output, accumulate, tensor mask on a channel range, 24 stored channels of the 32
+    r16 = to_nhwc_bf16(bf(rnd(N, 32, H, W, seed=7)), 32)
+    m = bf(rnd(N, 32, H, W, seed=9))
+    mb = to_nhwc_bf16(m, 64, 32)
+    acc0 = rnd(N, 24, H, W, seed=11)
+    o1, o2 = to_nhwc(acc0, 24).clone(), torch.zeros(N, H, W, 24, device="cuda")
+    w24 = K.conv_pack(w[:24].cuda(), False, cin, math=K.MATH_BF16)
+    K.conv_forward(K.Sl(xin, cin, 0), w24, b[:24].cuda(), K.Sl(o1), 3, alpha=0.2, res=K.Sl(r16, 24, 0), out2=K.Sl(o2), accumulate=True,
+                   mask=K.Sl(mb, 32, 32), mask_c0=8, mask_c1=16, math=K.MATH_BF16, tile_rows=rows)
+    pre = 0.2 * ref[:, :24]
+    want1 = pre + from_nhwc(r16.float())[:, :24] + acc0
+    want1[:, 8:16] = want1[:, 8:16] * (m[:, 8:16] > 0)
+    assert rel(from_nhwc(o2), pre) < TOL and rel(from_nhwc(o1), want1) < TOL
 
 
 @pytest.mark.parametrize("math_name", ["MATH_F32", "MATH_BF16"])

@@ -49,9 +49,29 @@ def oracle_135():
     return x, tgt, out.detach(), loss.item(), ora
 
 
+@pytest.fixture(scope="module")
+def oracle_135_f64(oracle_135):
+    """the same step with the oracle evaluated in float64: the yardstick that says how far an fp32 evaluation of this network
+    may sit from the exact gradient (conditioning), as opposed to how far two fp32 evaluations sit from each other"""
+    x, tgt = oracle_135[0], oracle_135[1]
+    _, ora = _pair(False, True)
+    ora = ora.double()
+    t0 = time.perf_counter()
+    F.mse_loss(ora(x.double()), tgt.double()).backward()
+    print(f"  oracle 135x240 train step in float64: {time.perf_counter() - t0:.1f} s")
+    return {n: p.grad.detach() for n, p in ora.named().items() if p.grad is not None}
+
+
 @pytest.mark.timeout(900)
-def test_135x240_training_step_fp32_every_gradient(oracle_135):
+def test_135x240_training_step_fp32_every_gradient(oracle_135, oracle_135_f64):
+    """Every one of the 131 gradients of the exact-fp32 mode against the fp32 CPU oracle: whole-tensor relative L2 and the
+    max-normalised element error both under 1e-3 - or, for a tensor that is not, ATTRIBUTED with the float64 oracle: the HIP
+    gradient may sit at most 4x as far from the float64 gradient as the fp32 CPU oracle itself does (+ 2e-5, the kernels'
+    own tolerance).  A tensor listed under that rule is one whose fp32 evaluation is ill-conditioned at this size (tiny
+    gradients formed by cancellation, ReLU pre-activations within rounding of zero), not one the kernels get wrong: an
+    ordering / accumulation defect would put the HIP gradient far from float64 where the CPU oracle is close."""
     x, tgt, o_out, o_loss, ora = oracle_135
+    g64 = oracle_135_f64
     net, _ = _pair(False, True)
     out = net(x.cuda())
     loss = F.mse_loss(out, tgt.cuda())
@@ -59,26 +79,31 @@ def test_135x240_training_step_fp32_every_gradient(oracle_135):
     assert (out.detach().cpu() - o_out).abs().max().item() < 1e-3
     assert abs(loss.item() - o_loss) < 1e-5 * o_loss
     onamed = ora.named()
-    over, num, den, worst = [], 0.0, 0.0, (None, 0.0)
+    listed, failed, num, den = [], [], 0.0, 0.0
     for n, p in net.named_parameters():
-        g, r = p.grad.detach().double().cpu(), onamed[n].grad.double()
+        g, r, t = p.grad.detach().double().cpu(), onamed[n].grad.double(), g64[n]
         e = ((g - r).abs().max() / r.abs().max().clamp_min(1e-300)).item()
         l2 = ((g - r).norm() / r.norm().clamp_min(1e-300)).item()
         num += float(((g - r) ** 2).sum())
         den += float((r ** 2).sum())
-        if e > worst[1]:
-            worst = (n, e)
-        if e >= 1e-3:
-            over.append((n, round(e, 5), round(l2, 5)))
-        # every tensor: whole-tensor relative L2 within 1e-3 (flow net: 1e-2, see below); no element off by 1e-2 of the max
-        assert l2 < (1e-2 if "motion_estimator" in n else 1e-3), (n, e, l2)
-        assert e < 2e-2, (n, e, l2)
+        if e < 1e-3 and l2 < 1e-3:
+            continue
+        # attribution: distance to the float64 gradient, max-normalised and whole-tensor L2, HIP vs the fp32 CPU oracle
+        tm, tn = t.abs().max().clamp_min(1e-300), t.norm().clamp_min(1e-300)
+        hip_e, ora_e = ((g - t).abs().max() / tm).item(), ((r - t).abs().max() / tm).item()
+        hip_l2, ora_l2 = ((g - t).norm() / tn).item(), ((r - t).norm() / tn).item()
+        row = (n, f"vs fp32 oracle: max {e:.2e} L2 {l2:.2e}", f"vs float64: HIP max {hip_e:.2e} L2 {hip_l2:.2e}, "
+               f"CPU fp32 max {ora_e:.2e} L2 {ora_l2:.2e}")
+        listed.append(row)
+        if not (hip_e <= 4 * ora_e + 2e-5 and hip_l2 <= 4 * ora_l2 + 2e-5):
+            failed.append(row)
     glob = (num / den) ** 0.5
-    print(f"  135x240 fp32: loss {loss.item():.7f} vs {o_loss:.7f}, worst tensor {worst}, over 1e-3: {over}, whole-vector rel L2 {glob:.2e}")
-    # (max-normalised element errors above 1e-3 are allowed for a few tensors: ReLU-mask flips of near-zero pre-activations,
-    # tests/test_sr_parity_gpu.py::test_cfg1_shape_against_oracle, and the 1e-4-sized gradient of the first attention conv -
-    # measured: attention.0.weight 2.3e-3 of its max at a whole-tensor L2 of 6e-4)
-    assert len(over) <= 3, over
+    print(f"  135x240 fp32: loss {loss.item():.7f} vs {o_loss:.7f}, whole-vector rel L2 {glob:.2e}; tensors over 1e-3 of the fp32 "
+          f"oracle, attributed with float64 ({len(listed)}):")
+    for row in listed:
+        print("    ", *row)
+    assert not failed, failed
+    assert len(listed) <= 12, listed          # (a handful of ill-conditioned tensors, not a systematic offset)
     assert glob < 1e-4
     sd = net.state_dict()
     for n in sr_oracle.buffer_shapes(64):
