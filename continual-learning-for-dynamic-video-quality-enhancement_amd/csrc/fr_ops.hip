@@ -281,9 +281,13 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------ max pooling
 // nn.MaxPool2d(k, s, p) / F.max_pool3d(x, (1, k, k)): the first maximum in (ky, kx) scan order wins, positions outside
 // the image are skipped.  idx[n, oy, ox, c] = ky * k + kx of the winner (one byte).
+// (BF, here and below: the tensors are stored as bf16.  A template parameter: as a run-time flag every ldx4 is a branch whose bf16
+// arm converts - waits for - its own load, so a thread's loads run one after the other.)
+template <bool BF>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int ld, int H, int W, int OH, int OW,
                                                           int k, int s, int pad, long total, float* __restrict__ out,
-                                                          uint8_t* __restrict__ idx, int bf) {
+                                                          uint8_t* __restrict__ idx) {
+    constexpr int bf = BF;
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -316,9 +320,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 }
 
 // gather form: every input pixel collects dy of the windows it won (fixed order, no atomics)
+template <bool BF>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           int ld, int H, int W, int OH, int OW, int k, int s, int pad,
-                                                          long total, float* __restrict__ dx, int bf) {
+                                                          long total, float* __restrict__ dx) {
+    constexpr int bf = BF;
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -351,8 +357,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ stride-2 subsampling
 // forward: out[n, y, x] = in[n, 2y, 2x]  (the input side of a 1x1 stride-2 convolution); backward: zero-insertion.
+template <bool BF>
 __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ in, int ld, int H, int W, int OH, int OW,
-                                                         long total, float* __restrict__ out, int backward, int bf) {
+                                                         long total, float* __restrict__ out, int backward) {
+    constexpr int bf = BF;
     const int g4 = ld >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -455,8 +463,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------ depth <-> space (block 2)
 // to_space: out[n, 2y+py, 2x+px, c] = in[n, y, x, (py*2+px)*Co + c]; to_depth: the inverse.  Co % 4 == 0.
+template <bool BF>
 __global__ __launch_bounds__(256) void depth_space2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
-                                                           int Co, long total, int to_depth, int bf) {
+                                                           int Co, long total, int to_depth) {
+    constexpr int bf = BF;
     const int g4 = Co >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;                       // total = N * 2H * 2W * g4
@@ -585,9 +595,11 @@ __global__ __launch_bounds__(256) void add_image_channel_kernel(float* __restric
 
 // dst[p, dst_coff + c] (+)= alpha * src[p, src_coff + c] for c < C (C % 4 == 0), either side fp32 or bf16: the storage-type
 // boundary between the bf16 stages of FrameRecoveryNet and its fp32 attention / fusion stages, and mean / broadcast over time
-__global__ __launch_bounds__(256) void cast_slice_kernel(float* __restrict__ dst, int dst_ld, int dst_coff, int dst_bf,
-                                                         const float* __restrict__ src, int src_ld, int src_coff, int src_bf,
+template <bool DB, bool SB>
+__global__ __launch_bounds__(256) void cast_slice_kernel(float* __restrict__ dst, int dst_ld, int dst_coff,
+                                                         const float* __restrict__ src, int src_ld, int src_coff,
                                                          int C, long total, float alpha, int accumulate) {
+    constexpr int dst_bf = DB, src_bf = SB;
     const int g4 = C >> 2;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
@@ -929,8 +941,12 @@ int nvq_maxpool_forward(const float* x, int ld, int N, int H, int W, int k, int 
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     NVQ_REQUIRE(OH > 0 && OW > 0, "maxpool_forward: empty output");
     const long total = (long)N * OH * OW * (ld / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, H, W, OH, OW, k, s, pad,
-                       total, out, idx, bf16);
+    if (bf16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, H, W, OH, OW, k,
+                           s, pad, total, out, idx);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, ld, H, W, OH, OW, k,
+                           s, pad, total, out, idx);
     return check_launch("maxpool_forward");
 }
 
@@ -939,8 +955,12 @@ int nvq_maxpool_backward(const float* dy, const uint8_t* idx, int ld, int N, int
     NVQ_REQUIRE(ld % 4 == 0 && k >= 1 && k <= 7 && s >= 1 && pad * 2 <= k, "maxpool_backward: args");
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     const long total = (long)N * H * W * (ld / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, ld, H, W, OH, OW, k, s,
-                       pad, total, dx, bf16);
+    if (bf16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, ld, H, W, OH,
+                           OW, k, s, pad, total, dx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, ld, H, W, OH,
+                           OW, k, s, pad, total, dx);
     return check_launch("maxpool_backward");
 }
 
@@ -948,8 +968,12 @@ int nvq_subsample2(const float* in, int ld, int N, int H, int W, float* out, int
     NVQ_REQUIRE(ld % 4 == 0 && N > 0 && H > 0 && W > 0, "subsample2: args");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const long total = backward ? (long)N * H * W * (ld / 4) : (long)N * OH * OW * (ld / 4);
-    hipLaunchKernelGGL(subsample2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, ld, H, W, OH, OW, total, out,
-                       backward, bf16);
+    if (bf16)
+        hipLaunchKernelGGL(subsample2_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, ld, H, W, OH, OW,
+                           total, out, backward);
+    else
+        hipLaunchKernelGGL(subsample2_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, ld, H, W, OH, OW,
+                           total, out, backward);
     return check_launch("subsample2");
 }
 
@@ -971,8 +995,12 @@ int nvq_bilinear_resize(const float* in, int ld, int N, int H, int W, int OH, in
 int nvq_depth_space2(const float* in, float* out, int N, int H, int W, int Co, int to_depth, int bf16, void* stream) {
     NVQ_REQUIRE(Co % 4 == 0 && N > 0 && H > 0 && W > 0, "depth_space2: Co %d", Co);
     const long total = (long)N * 2 * H * 2 * W * (Co / 4);
-    hipLaunchKernelGGL(depth_space2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, Co, total,
-                       to_depth, bf16);
+    if (bf16)
+        hipLaunchKernelGGL(depth_space2_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, Co,
+                           total, to_depth);
+    else
+        hipLaunchKernelGGL(depth_space2_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, Co,
+                           total, to_depth);
     return check_launch("depth_space2");
 }
 
@@ -1037,8 +1065,12 @@ int nvq_cast_slice(float* dst, int dst_ld, int dst_coff, int dst_bf16, const flo
     NVQ_REQUIRE(C > 0 && C % 4 == 0 && dst_ld % 4 == 0 && dst_coff % 4 == 0 && src_ld % 4 == 0 && src_coff % 4 == 0 &&
                     dst_coff + C <= dst_ld && src_coff + C <= src_ld, "cast_slice: C %d ld %d/%d", C, dst_ld, src_ld);
     const long total = npix * (C / 4);
-    hipLaunchKernelGGL(cast_slice_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, dst_coff, dst_bf16,
-                       src, src_ld, src_coff, src_bf16, C, total, alpha, accumulate);
+#define NVQ_CAST(DB, SB)                                                                                                  \
+    hipLaunchKernelGGL((cast_slice_kernel<DB, SB>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld, \
+                       dst_coff, src, src_ld, src_coff, C, total, alpha, accumulate)
+    if (dst_bf16) { if (src_bf16) NVQ_CAST(true, true); else NVQ_CAST(true, false); }
+    else { if (src_bf16) NVQ_CAST(false, true); else NVQ_CAST(false, false); }
+#undef NVQ_CAST
     return check_launch("cast_slice");
 }
 

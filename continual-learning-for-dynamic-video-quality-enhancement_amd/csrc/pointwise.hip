@@ -623,8 +623,9 @@ constexpr int DB_MAXWG = 512;
 // registers (32 for the BatchNorm parameters) counted against the 128-register budget of every launch.
 // EPI: 0 no epilogue, 1 the general one (storage types as run-time flags), 2 add and mask both present and both bf16 - their
 // two 8-byte loads are then issued together (behind a run-time flag each is a branch that waits for its own load).
+// (HAS_BN with EPI = 2 needs 131 registers: three waves per SIMD instead of 12 bytes of scratch behind the prefetch)
 template <bool HAS_BN, int EPI>
-__global__ __launch_bounds__(DB_T, 4) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
+__global__ __launch_bounds__(DB_T, (HAS_BN && EPI == 2 ? 3 : 4)) void dwconv_bf16_kernel(const __bf16* __restrict__ in, int in_ld,
                                                            const float* __restrict__ weight, int C,
                                                            float* __restrict__ out, int out_ld, int H, int W, int tilesX,
                                                            int tilesY, int ntiles, int flip, int out_bf16, DwBn bn, DwEpi ep) {
@@ -1065,11 +1066,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 // ---------------------------------------------------------------- slice axpy
+template <bool SB>   // the source is stored as bf16 (a template parameter: see warp_fwd_kernel)
 __global__ __launch_bounds__(256) void axpy_slice_kernel(float* __restrict__ dst, int dst_ld, int dst_coff,
                                                          const float* __restrict__ src, int src_ld,
                                                          int src_coff, const float* __restrict__ mask,
                                                          int mask_ld, int mask_coff, int C, float alpha,
-                                                         int accumulate, long total, int src_bf16) {
+                                                         int accumulate, long total) {
+    constexpr int src_bf16 = SB;
     const long gid = blockIdx.x * 256L + threadIdx.x;
     if (gid >= total) return;
     const int C4 = C >> 2;
@@ -1413,8 +1416,12 @@ int nvq_axpy_slice(float* dst, int dst_ld, int dst_coff, const float* src, int s
                 "axpy_slice: alignment (C %d ld %d/%d)", C, dst_ld, src_ld);
     const long total = npix * (C / 4);
     if (total == 0) return NVQ_OK;
-    hipLaunchKernelGGL(axpy_slice_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld,
-                       dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total, src_bf16);
+    if (src_bf16)
+        hipLaunchKernelGGL(axpy_slice_kernel<true>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld,
+                           dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total);
+    else
+        hipLaunchKernelGGL(axpy_slice_kernel<false>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dst, dst_ld,
+                           dst_coff, src, src_ld, src_coff, mask, mask_ld, mask_coff, C, alpha, accumulate, total);
     return check_launch("axpy_slice");
 }
 

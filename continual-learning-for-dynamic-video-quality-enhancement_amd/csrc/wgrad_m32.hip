@@ -575,7 +575,8 @@ bool wgrad_m32_takes(const nvq_wgrad_desc& d) {
     if ((size_t)(d.x_plane ? (size_t)nci * d.x_plane : (size_t)d.n * d.h * d.w * d.x_ld) >= ((size_t)1 << 32) ||
         (size_t)d.n * d.h * d.w * d.dy_ld >= ((size_t)1 << 31))
         return false;
-    if (d.ksize == 3) return d.x_plane && d.cout == 32 && nci >= 2 && nci <= 6 && d.cin >= d.x_ld;
+    // (3x3 with 64 input channels: equal in isolation, 15 % slower than the split kernel inside the training step)
+    if (d.ksize == 3) return d.x_plane && d.cout == 32 && nci >= 3 && nci <= 6 && d.cin >= d.x_ld;
     // 1x1: 64 .. 256 input channels, 32 / 64 output channels; slice-planar or interleaved x
     return nci >= 2 && nci <= 8 && nco <= 2 && (!d.x_plane || d.cin >= d.x_ld);
 }

@@ -187,9 +187,10 @@ def test_train_with_ewc_loop_in_the_scripts_default_mode(golden_dir):
     for r in sorted(rows, key=lambda r: -r[2])[:5]:
         print(f"    {r[0]}: cosine {r[1]:.5f}, sum off by {r[2]:.3f}")
     assert worst_cos >= 0.99, [r for r in rows if r[1] < 0.99]
-    # a Fisher entry is a squared gradient: 5 % on a tensor's sum is a 2.5 % gradient error.  Measured: every tensor within 5 %
-    # except the first attention conv (6.3 %: its gradients are the smallest of the net, 1e-6 of the upsampler's, formed behind
-    # the softmax from bf16-stored feature tensors); bound 8 % per tensor, 5 % on the whole Fisher
+    # a Fisher entry is a squared gradient: 5 % on a tensor's sum is a 2.5 % gradient error.  Measured: task loss 8e-4, EWC loss
+    # 5e-3, min cosine 0.9918, whole Fisher 0.5 %, every tensor's sum within 3.5 % except the first attention conv (bias 7.0 %,
+    # weight 6.3 %: the smallest gradients of the net, formed behind the softmax from bf16-stored feature tensors); bound 8 %
+    # per tensor, 5 % on the whole Fisher
     assert worst_sum <= 0.08, [r for r in rows if r[2] > 0.08]
     assert abs(tot16 / tot_ref - 1) <= 0.05
 

@@ -688,8 +688,8 @@ def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     assert rel(db, dy.sum((0, 2, 3))) < TOL
 
 
-@pytest.mark.parametrize("Fc,cin,N,H,W", [(64, 64, 2, 16, 64), (64, 96, 1, 21, 45), (64, 128, 2, 9, 33), (64, 160, 3, 17, 70),
-                                            (64, 192, 1, 40, 96), (32, 64, 2, 8, 32), (32, 160, 1, 13, 50), (128, 192, 1, 12, 40),
+@pytest.mark.parametrize("Fc,cin,N,H,W", [(64, 96, 2, 16, 64), (64, 96, 1, 21, 45), (64, 128, 2, 9, 33), (64, 160, 3, 17, 70),
+                                            (64, 192, 1, 40, 96), (32, 96, 2, 8, 32), (32, 160, 1, 13, 50), (128, 192, 1, 12, 40),
                                             (64, 192, 5, 37, 130)])
 def test_conv_bf16_weight_gradient_all_input_channels(K, Fc, cin, N, H, W):
     """nvq_conv_wgrad on a slice-planar bf16 dense-block buffer, 3x3, cout = 32: the all-input-channel kernel (wgrad_m32.hip: x
