@@ -12,13 +12,14 @@
 // algorithmic bytes issued, of which the dy rows two consecutive units share are L2 hits.
 //
 // One persistent workgroup per CU (XCD-ordered tiles, two units per 4 x 32 tile), eight waves, one s_barrier per unit:
-//   * six CONSUMER waves hold the accumulators (cin x 32 x 9 fp32 = 221 KB for cin = 192): wave (grp, ky) owns the three kx
-//     taps of row ky for CB 32-channel blocks; M = ci, N = co, K = 16 pixels of a unit row, both operands transposed out of
-//     [pixel][channel] LDS images by ds_read_b64_tr_b16, the fragments of K step k + 1 read under the MFMAs of step k - across
-//     units too: the barrier that hands unit u + 1 over sits in front of unit u's last MFMA batch;
-//   * two more waves stage dy (with its halo) and sum it for the bias gradient (fp32, from the staged values);
-//   * ALL eight waves stage x: three 16-byte loads and three LDS stores per wave and unit, two units ahead in two register sets
-//     (unit u + 1 is stored into the slot the consumers left one barrier ago, then the loads of unit u + 3 are issued).
+//   * every wave holds accumulators: the 9 taps x 2 groups of CB 32-channel blocks are 18 (group, tap) jobs of CB accumulator
+//     blocks (M = ci, N = co, K = 16 pixels of a unit row; both operands transposed out of [pixel][channel] LDS images by
+//     ds_read_b64_tr_b16).  Waves w and w + 4 share a SIMD: six waves take two jobs, waves 2 and 3 three (12 / 12 / 15 / 15 jobs
+//     per SIMD).  The fragments of K step k + 1 are read under the MFMAs of step k - across units too: the barrier that hands
+//     unit u + 1 over sits in front of unit u's last MFMA batch;
+//   * ALL eight waves stage x (three 16-byte loads and three LDS stores per wave and unit), the six two-job waves also dy (with
+//     its halo; they sum it for the bias gradient, fp32, from the staged values): two units ahead in two register sets, unit
+//     u + 2 stored into the slot unit u was read from right behind barrier u + 1's last MFMA batch, then the loads of unit u + 4.
 // Loads are inline asm (uniform base + per-lane offset: one instruction) with counted s_waitcnt vmcnt by hand: with register
 // sets that rotate over loop iterations the compiler's own bookkeeping drains vmcnt(0) in front of every store pass.
 //
@@ -26,16 +27,19 @@
 // registers spills behind 144 accumulators; (2) both tiles by LDS-DMA (global_load_lds_dwordx4, three units ahead, counted
 // vmcnt): correct, 1.08x the bytes, but DMA alone 318 us + MFMAs alone 392 us = 582 us together - a DMA piece costs the issuing
 // wave ~200 cycles in an MFMA phase whether its data comes from HBM or L2; (3) two dedicated producer waves (registers, two or
-// three units ahead): s_memtime stamps show them taking 3400 cycles per unit for 13 loads + 13 LDS stores each while the
-// consumers compute for 1500 and wait - ANY memory instruction issued next to a dense MFMA stream costs its wave 100 - 200
-// cycles, so the instruction count per wave is what matters: spread over all eight waves 496 us, the dy waves at s_setprio 3
-// 482 - 492 us against 565 - 595 us of the split kernel.  What bounds it now: the two SIMDs that hold two consumers each run
-// 2 x 36 MFMAs = 2304 cycles per unit at the ~1.5 - 1.75 GHz the chip holds under this load (MFMAs alone, nothing staged: 372 us).
+// three units ahead) + six MFMA waves: s_memtime stamps show the producers taking 3400 cycles per unit for 13 loads + 13 LDS
+// stores each while the consumers compute for 1500 and wait; (4) the memory instructions spread over all eight waves: 496 us,
+// 482 - 492 with the dy waves at s_setprio 3; (5) the MFMA jobs spread over all eight waves as above: 473 us against 565 - 595
+// of the split kernel.  What bounds it: the staging of a unit - 40 loads and 40 LDS stores of 1 KiB through the CU's one
+// address pipe and LDS store path - takes the waves 700 - 1900 cycles of a 3300-cycle unit wherever it is placed (in the middle
+// of the unit between other waves' MFMAs, or with all waves at once where no MFMA is in flight), next to ~1900 cycles of MFMAs
+// on the busiest SIMD at the 1.5 - 1.75 GHz the chip holds under this load.
 // Partial slabs / bias partials in the layout of wgrad_bf16_kernel; the same reduce kernel finishes.
 //
 // LDS images.  x unit: [32-channel block][64 pixels][64 B] (the four pixels x two 16-channel blocks of a half-wave's transposing
 // read are 256 contiguous bytes = all 64 banks); a load instruction covers 16 pixels of one block (a compact plane: 1 KiB
 // contiguous in memory; a block of the leading tensor: 64 B of every pixel).  dy of a unit: [4 x 34 halo pixels][64 B].
+#include <type_traits>
 #include "conv_common.h"
 
 namespace nvq {
@@ -46,13 +50,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 constexpr int WM_TR = 4;                 // tile rows
-constexpr int WM_NCONS = 6, WM_NPROD = 2;
-constexpr int WM_NTHR = 64 * (WM_NCONS + WM_NPROD);
-constexpr int WM_PT = 64 * WM_NPROD;     // producer threads
+constexpr int WM_NTHR = 512;             // eight waves
 constexpr int WM_HW = TW + 2, WM_HH = 2 + 2, WM_NPY = WM_HW * WM_HH;       // dy of a unit with halo: 34 x 4
 constexpr int WM_YBYTES = WM_NPY * 64;
 constexpr int WM_UPX = 2 * TW;           // pixels of a unit (two tile rows)
-constexpr int WM_YPP = (WM_NPY * 4 + WM_PT - 1) / WM_PT;                    // dy pieces per producer thread and unit (5)
+constexpr int WM_DYT = 384;              // threads (six waves) that stage dy: 544 pieces per unit -> two each (the second mostly a dummy)
 
 // Producer loads and their waits by hand (cdna_hip_programming.md 5.7): with register sets that rotate over the iterations of
 // a loop the compiler's own s_waitcnt bookkeeping drains vmcnt(0) in front of every LDS write pass - i.e. every unit in flight -
@@ -73,7 +75,7 @@ __device__ __forceinline__ void hold(u32x4& r) { asm volatile("" : "+v"(r)); }  
 
 template <int NCI>
 struct WmCfg {
-    static constexpr int CB = NCI <= 2 ? 1 : (NCI <= 4 ? 2 : 3);       // 32-channel blocks per consumer wave
+    static constexpr int CB = (NCI + 1) / 2;                            // 32-channel blocks per wave (two block groups)
     static constexpr int UBYTES = WM_UPX * NCI * 64;                    // x bytes of a unit
     static constexpr int XPIECES = WM_UPX * NCI * 4;                    // its 16-byte pieces ...
     static constexpr int XPT = (XPIECES + WM_NTHR - 1) / WM_NTHR;       // ... per thread (ALL eight waves stage x)
@@ -82,12 +84,12 @@ struct WmCfg {
 
 }  // namespace
 
-// cout = 32, cin = 32 NCI, slice-planar bf16 x (nvq_wgrad_desc::x_plane), bf16 dy.
+// cout = 32, cin = 32 NCI (3 <= NCI <= 6), slice-planar bf16 x (nvq_wgrad_desc::x_plane), bf16 dy.
 template <int NCI>
 __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_desc d, int tilesX, int tilesY, int ntiles) {
     using C = WmCfg<NCI>;
     constexpr int CB = C::CB, XPT = C::XPT;
-    static_assert(C::LDS <= 160 * 1024 && C::LDS >= WM_PT * 32, "LDS");
+    static_assert(C::LDS <= 160 * 1024 && C::LDS >= WM_DYT * 32 && NCI >= 2 && NCI <= 6, "configuration");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[C::LDS];
     constexpr int YOFF = 2 * C::UBYTES;
 
@@ -99,17 +101,30 @@ __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_d
     const int mytiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
     const int U = 2 * mytiles;                                // units of this workgroup: rows 2 (u & 1), + 1 of its tile u >> 1
     const __bf16* x16 = reinterpret_cast<const __bf16*>(d.x);
+    const __bf16* dy16 = reinterpret_cast<const __bf16*>(d.dy);
     const int LU = d.x_ld >> 5;                               // 32-channel blocks of the leading tensor
+
+    // ---- roles.  The 9 taps x 2 block groups are 18 (group, tap) jobs of CB accumulator blocks each.  Waves w and w + 4 share
+    // a SIMD: waves 0, 1, 4, 5 (two MFMA waves per SIMD) and 6, 7 take two jobs, waves 2, 3 (next to 6, 7) three:
+    //   group 0 (blocks [0, CB)):   wave 0: taps 0, 1   wave 1: 2, 3   wave 6: 4, 5   wave 2: 6, 7, 8
+    //   group 1 (blocks [CB, NCI)): wave 4: taps 0, 1   wave 5: 2, 3   wave 7: 4, 5   wave 3: 6, 7, 8
+    // = 12 / 12 / 15 / 15 jobs' worth of MFMAs per SIMD instead of the 18 / 18 / 9 / 9 of six equal MFMA waves.  The six
+    // two-job waves also stage dy (with its halo) and sum it for the bias gradient; all eight stage x.
+    const bool three = wave == 2 || wave == 3;
+    const int grp = (wave == 0 || wave == 1 || wave == 2 || wave == 6) ? 0 : 1;
+    const int tap0 = three ? 6 : (wave == 6 || wave == 7) ? 4 : 2 * (wave & 1);
+    const int dyw = wave < 2 ? wave : (wave < 6 ? wave - 2 : wave - 2);     // index among the dy-staging waves (waves 2, 3: unused)
+    const int cb0 = grp * CB;
+    const int ncb = NCI - cb0 < CB ? NCI - cb0 : CB;
 
     // ---- x staging, by every wave: piece j = tid + 512 k of a unit image [block][64 px][4 pieces] -> block (tid >> 8) + 2 k
     // (wave-uniform), unit row (tid >> 7) & 1 (wave-uniform), column (tid >> 2) & 31, piece tid & 3; its LDS address is linear
-    // in j.  A load is one instruction: uniform base + one of two per-lane byte offsets.  (A memory instruction issued next to
-    // a dense MFMA stream costs its wave ~100 cycles - s_memtime stamps: two dedicated producer waves needed 3400 cycles per
-    // unit for 13 loads + 13 LDS stores each while the consumers computed for 1500 and waited - so the instructions are spread
-    // over all eight waves: three loads and three stores per wave and unit.)
+    // in j.  A load is one instruction: uniform base + one of two per-lane byte offsets.
     const int xcol = (tid >> 2) & 31, xsub = tid & 3, xrow = (wave >> 1) & 1, xblk0 = wave >> 2;   // (row, block: from the SGPR)
     const unsigned v_lead = (unsigned)((xcol * d.x_ld + 8 * xsub) * 2), v_plane = (unsigned)((xcol * 32 + 8 * xsub) * 2);
-    struct XSet { u32x4 x[XPT]; bool full, ok; };          // ok: this lane's pixel exists (always, in a full unit)
+    // dy staging, by the six two-job waves: piece j = dt + 384 k (k < 2) of the unit's [4 x 34 halo pixels][4 pieces]
+    const int dt = (wave < 2 ? wave : wave - 2) * 64 + lane;  // 0 .. 383 (waves 2, 3 never use it)
+    struct Set { u32x4 x[XPT]; u32x4 y[2]; bool xok; unsigned char yok; };
     // Units are loaded in order; the tile of the next one is kept decoded: consecutive tiles of a workgroup are G / 8 apart in the
     // XCD order (xcd_tile(bid + k G) = xcd_tile(bid) + k G / 8 for G % 8 == 0), so (n, ty, tx) advance by carries - the two
     // divisions of a from-scratch decode are ~80 scalar instructions per unit in every wave.
@@ -121,50 +136,12 @@ __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_d
         c_n = bt / tilesY;
     }
     const int c_step = G >> 3;
-    auto unit_origin = [&](int u, int& n, int& y0, int& x0) {  // u = c_unit or c_unit + 1 (monotonic callers)
-        if ((u >> 1) != (c_unit >> 1)) {
-            if ((G & 7) == 0) {
-                c_tx += c_step;
-                while (c_tx >= tilesX) { c_tx -= tilesX; ++c_ty; }
-                while (c_ty >= tilesY) { c_ty -= tilesY; ++c_n; }
-            } else {                                          // (a handful of workgroups: decode from scratch)
-                int bt = xcd_tile((int)blockIdx.x + (u >> 1) * G, ntiles);
-                c_tx = bt % tilesX; bt /= tilesX;
-                c_ty = bt % tilesY;
-                c_n = bt / tilesY;
-            }
-        }
-        c_unit = u;
-        n = c_n; y0 = c_ty * WM_TR + 2 * (u & 1); x0 = c_tx * TW;
-    };
-    auto load_x = [&](int u, XSet& st) {                      // exactly XPT loads (a piece past the image / the unit: a dummy)
-        int n, y0, x0;
-        unit_origin(u, n, y0, x0);
-        const bool row_ok = y0 + xrow < H;                    // (wave-uniform)
-        const unsigned rel = (unsigned)((n * H + (row_ok ? y0 + xrow : y0)) * W + x0);
-        st.full = x0 + TW <= W && y0 + 2 <= H;                // (uniform)
-        st.ok = row_ok && xcol < W - x0;
-        const unsigned vl = st.ok ? v_lead : 0u, vp = st.ok ? v_plane : 0u;
+    float bsum[8];
 #pragma unroll
-        for (int k = 0; k < XPT; ++k) {
-            const int blk = xblk0 + 2 * k < NCI ? xblk0 + 2 * k : 0;       // (wave-uniform; past the unit: block 0 again, not stored)
-            if (blk < LU) gload16s(st.x[k], x16 + (size_t)(rel * (unsigned)d.x_ld + 32u * blk), vl);
-            else gload16s(st.x[k], x16 + ((size_t)blk * d.x_plane + rel * 32u), vp);
-        }
-    };
-    auto write_x = [&](int u, XSet& st) {                     // (behind a vm_wait that covers st's loads)
-        unsigned char* slot = lds + (u & 1) * C::UBYTES + tid * 16;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < XPT; ++k) {
-            hold(st.x[k]);
-            if (xblk0 + 2 * k < NCI) *reinterpret_cast<u32x4*>(slot + k * (WM_NTHR * 16)) = st.ok ? st.x[k] : z;
-        }
-    };
-    XSet xa, xb;                                              // even / odd units
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 #ifdef NVQ_WM_STAMPS
     // (development build: s_memtime stamps of workgroup 0, wave w's k-th stamp at stamps[w * 2048 + k]; tools/wgrad_stamps2.py)
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C + 512 * 256);   // (behind the official workspace)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C + 512 * 256);
     int nst = 0;
     const bool stamping = (d.variant & 128) && blockIdx.x == 0 && lane == 0;
     auto stamp = [&]() {
@@ -173,150 +150,139 @@ __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_d
 #else
     auto stamp = [&]() {};
 #endif
-    float bsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    if (wave >= WM_NCONS) {
-        // ================================================================ the two waves that also stage dy and sum it
-        const int pt = tid - 64 * WM_NCONS;                   // 0 .. 127
-        __builtin_amdgcn_s_setprio(3);                        // their memory instructions ahead of the co-resident consumer's MFMAs (-4 %)
-        const __bf16* dy16 = reinterpret_cast<const __bf16*>(d.dy);
-        const int sub = pt & 3;
-        // dy piece k: j = pt + 128 k -> halo pixel j >> 2 (row hr, column hc), piece pt & 3
-        unsigned short ypos[WM_YPP];
-        unsigned yvoff[WM_YPP];                               // byte offset of the piece from the unit's halo origin (y0 - 1, x0 - 1)
-        unsigned yin = 0;                                     // bit k: piece k is one of the unit's own pixels (not halo)
+    // One role = one instantiation: NT taps per wave, DY: the wave stages dy.  (Separate top-level branches: accumulators that
+    // are live across two copies of a loop in ONE branch make the register allocator spill.)
+    auto role = [&](auto nt_tag, auto dy_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr bool DY = decltype(dy_tag)::value;
+        constexpr int S = XPT + (DY ? 2 : 0);                 // loads per unit and thread (always exactly S: counted waits)
+        // dy pieces of this thread: halo pixel hp (row hr, column hc), 16-byte piece dt & 3
+        int yhr[2] = {0, 0}, yhc[2] = {0, 0};
+        unsigned yvoff[2] = {0u, 0u}, yin = 0, yreal = 0;
+        if constexpr (DY) {
 #pragma unroll
-        for (int k = 0; k < WM_YPP; ++k) {
-            const int hp = (pt >> 2) + 32 * k;
-            const int hr = hp / WM_HW, hc = hp - hr * WM_HW;
-            ypos[k] = (unsigned short)(hp < WM_NPY ? hr << 8 | hc : 0xffff);
-            yvoff[k] = hp < WM_NPY ? (unsigned)(((hr * W + hc) * d.dy_ld + 8 * sub) * 2) : 0u;
-            yin |= ((hp < WM_NPY && hr >= 1 && hr <= 2 && hc >= 1 && hc <= TW) ? 1u : 0u) << k;
+            for (int k = 0; k < 2; ++k) {
+                const int j = dt + WM_DYT * k, hp = j >> 2;
+                const bool real = hp < WM_NPY;
+                yhr[k] = real ? hp / WM_HW : 0;
+                yhc[k] = real ? hp - yhr[k] * WM_HW : 0;
+                yvoff[k] = (unsigned)(((yhr[k] * W + yhc[k]) * d.dy_ld + 8 * (dt & 3)) * 2);   // from the halo origin (y0 - 1, x0 - 1)
+                yreal |= (real ? 1u : 0u) << k;
+                yin |= ((real && yhr[k] >= 1 && yhr[k] <= 2 && yhc[k] >= 1 && yhc[k] <= TW) ? 1u : 0u) << k;
+            }
         }
-        const int ysub = d.dy_coff + 8 * sub;
-        struct YSet { u32x4 y[WM_YPP]; unsigned ymask, ymask_in; bool full; };
-        YSet ya, yb;
-        constexpr int S = XPT + WM_YPP;                       // loads per unit and thread (always exactly S: counted waits)
-        // the unit's dy rows y0 - 1 .. y0 + 2 with a column of halo on either side (the two rows it shares with the
-        // neighbouring unit are fetched by both: L2 hits one unit later); full: the whole halo lies inside the image
-        auto load_y = [&](int u, YSet& st) {
-            int n, y0, x0;
-            unit_origin(u, n, y0, x0);
-            const unsigned pix0 = (unsigned)((n * H + y0) * W + x0);
-            st.full = x0 >= 1 && x0 + TW + 1 <= W && y0 >= 1 && y0 + 3 <= H;
-            if (st.full) {
-                const __bf16* ybase = dy16 + ((long)(pix0 - W - 1) * d.dy_ld + d.dy_coff);
+        auto load = [&](int u, Set& st) {                     // exactly S loads (a piece that does not exist: a dummy)
+            if ((u >> 1) != (c_unit >> 1)) {
+                if ((G & 7) == 0) {
+                    c_tx += c_step;
+                    while (c_tx >= tilesX) { c_tx -= tilesX; ++c_ty; }
+                    while (c_ty >= tilesY) { c_ty -= tilesY; ++c_n; }
+                } else {                                      // (a handful of workgroups: decode from scratch)
+                    int bt = xcd_tile((int)blockIdx.x + (u >> 1) * G, ntiles);
+                    c_tx = bt % tilesX; bt /= tilesX;
+                    c_ty = bt % tilesY;
+                    c_n = bt / tilesY;
+                }
+            }
+            c_unit = u;
+            const int y0 = c_ty * WM_TR + 2 * (u & 1), x0 = c_tx * TW;
+            {
+                const bool row_ok = y0 + xrow < H;            // (wave-uniform)
+                const unsigned rel = (unsigned)((c_n * H + (row_ok ? y0 + xrow : y0)) * W + x0);
+                st.xok = row_ok && xcol < W - x0;
+                const unsigned vl = st.xok ? v_lead : 0u, vp = st.xok ? v_plane : 0u;
 #pragma unroll
-                for (int k = 0; k < WM_YPP; ++k) gload16s(st.y[k], ybase, yvoff[k]);
-            } else {
-                const long ypix0 = (long)pix0 * d.dy_ld;
-                st.ymask = 0; st.ymask_in = 0;
+                for (int k = 0; k < XPT; ++k) {
+                    const int blk = xblk0 + 2 * k < NCI ? xblk0 + 2 * k : 0;   // (wave-uniform; past the unit: block 0 again, not stored)
+                    if (blk < LU) gload16s(st.x[k], x16 + (size_t)(rel * (unsigned)d.x_ld + 32u * blk), vl);
+                    else gload16s(st.x[k], x16 + ((size_t)blk * d.x_plane + rel * 32u), vp);
+                }
+            }
+            if constexpr (DY) {
+                // the unit's dy rows y0 - 1 .. y0 + 2 with a column of halo on either side (the two rows it shares with the
+                // neighbouring unit are fetched by both: L2 hits one unit later)
+                const long pix0 = (long)(c_n * H + y0) * W + x0;
+                if (x0 >= 1 && x0 + TW + 1 <= W && y0 >= 1 && y0 + 3 <= H) {   // (uniform) the whole halo lies inside the image
+                    st.yok = (unsigned char)yreal;
+                    const __bf16* ybase = dy16 + ((pix0 - W - 1) * d.dy_ld + d.dy_coff);
 #pragma unroll
-                for (int k = 0; k < WM_YPP; ++k) {
-                    const int hr = ypos[k] >> 8, hc = ypos[k] & 0xff;
-                    const int gy = y0 + hr - 1, gx = x0 + hc - 1;
-                    const bool ok = ypos[k] != 0xffff && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                    st.ymask |= (ok ? 1u : 0u) << k;
-                    st.ymask_in |= ((ok && ((yin >> k) & 1)) ? 1u : 0u) << k;
-                    gload16(st.y[k], dy16 + (ok ? ypix0 + (((hr - 1) * W + (hc - 1)) * d.dy_ld + ysub) : (long)d.dy_coff));
+                    for (int k = 0; k < 2; ++k) gload16s(st.y[k], ybase, (yreal >> k) & 1 ? yvoff[k] : 0u);
+                } else {
+                    st.yok = 0;
+                    const __bf16* ybase = dy16 + d.dy_coff;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int gy = y0 + yhr[k] - 1, gx = x0 + yhc[k] - 1;
+                        const bool ok = ((yreal >> k) & 1) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                        st.yok |= (ok ? 1u : 0u) << k;
+                        gload16s(st.y[k], ybase, ok ? (unsigned)((((long)(c_n * H + gy) * W + gx) * d.dy_ld + 8 * (dt & 3)) * 2) : 0u);
+                    }
                 }
             }
         };
-        auto write_y = [&](int u, YSet& st) {
-            unsigned char* ys = lds + YOFF + (u & 1) * WM_YBYTES + pt * 16;
+        auto write = [&](int u, Set& st) {                    // (behind a vm_wait that covers st's loads)
             const u32x4 z = {0u, 0u, 0u, 0u};
-            const unsigned vmask = st.full ? 0xffffffffu : st.ymask, imask = st.full ? yin : st.ymask_in;
+            unsigned char* slot = lds + (u & 1) * C::UBYTES + tid * 16;
 #pragma unroll
-            for (int k = 0; k < WM_YPP; ++k) {
-                hold(st.y[k]);
-                if (ypos[k] == 0xffff) continue;
-                const u32x4 v = (vmask >> k) & 1 ? st.y[k] : z;
-                *reinterpret_cast<u32x4*>(ys + k * (WM_PT * 16)) = v;
-                if ((imask >> k) & 1) {                       // the unit's own pixels: what the bias gradient sums, once per pixel
-                    bsum[0] += bf_lo(v[0]); bsum[1] += bf_hi(v[0]); bsum[2] += bf_lo(v[1]); bsum[3] += bf_hi(v[1]);
-                    bsum[4] += bf_lo(v[2]); bsum[5] += bf_hi(v[2]); bsum[6] += bf_lo(v[3]); bsum[7] += bf_hi(v[3]);
+            for (int k = 0; k < XPT; ++k) {
+                hold(st.x[k]);
+                if (xblk0 + 2 * k < NCI) *reinterpret_cast<u32x4*>(slot + k * (WM_NTHR * 16)) = st.xok ? st.x[k] : z;
+            }
+            if constexpr (DY) {
+                unsigned char* ys = lds + YOFF + (u & 1) * WM_YBYTES + dt * 16;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    hold(st.y[k]);
+                    if (!((yreal >> k) & 1)) continue;
+                    const u32x4 v = (st.yok >> k) & 1 ? st.y[k] : z;
+                    *reinterpret_cast<u32x4*>(ys + k * (WM_DYT * 16)) = v;
+                    if ((yin >> k) & 1) {                     // the unit's own pixels: what the bias gradient sums, once per pixel
+                        bsum[0] += bf_lo(v[0]); bsum[1] += bf_hi(v[0]); bsum[2] += bf_lo(v[1]); bsum[3] += bf_hi(v[1]);
+                        bsum[4] += bf_lo(v[2]); bsum[5] += bf_hi(v[2]); bsum[6] += bf_lo(v[3]); bsum[7] += bf_hi(v[3]);
+                    }
                 }
             }
         };
-        auto hand_over = [&]() {                              // this wave's LDS stores are done; meet the others
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        };
-        // while the consumers compute unit u: unit u + 1 -> the slot they left one barrier ago, then the loads of unit u + 3
-        auto body = [&](int u, XSet& xs, YSet& ys) {          // the sets hold unit u + 1; behind them unit u + 2 was loaded
-            if (u + 1 >= U) return;
-            if (u + 2 < U) vm_wait<S>(); else vm_wait<0>();
-            stamp();
-            write_x(u + 1, xs);
-            write_y(u + 1, ys);
-            stamp();
-            if (u + 3 < U) { load_x(u + 3, xs); load_y(u + 3, ys); }
-            stamp();
-            hand_over();                                      // barrier u + 1
-            stamp();
-        };
-        if (U > 0) {
-            load_x(0, xa); load_y(0, ya);
-            load_x(1, xb); load_y(1, yb);
-            vm_wait<S>();
-            write_x(0, xa); write_y(0, ya);
-            if (2 < U) { load_x(2, xa); load_y(2, ya); }
-            hand_over();                                      // barrier 0: unit 0 is in its slot
-#pragma unroll 1
-            for (int u = 0; u < U; u += 2) {
-                body(u, xb, yb);
-                body(u + 1, xa, ya);
-            }
-        }
-    } else {
-        // ================================================================ consumers
+        // ---- MFMA side.  A transposing read: lane (r = (q, p), hb) supplies the address of image row pix + q, columns 4p ..
+        // 4p+3 of a 16-channel block and receives channel r of that block for pixels pix .. pix + 3; two reads (pix, pix + 4) =
+        // the 8 k values 8h .. 8h + 7 of an operand.  A wave of group 1 may own fewer than CB blocks (NCI = 3, 5): it runs the
+        // MFMAs of a phantom block on block 0's fragments and never writes that accumulator - the K loop stays free of branches.
         const int r = lane & 15, hb = (lane >> 4) & 1, h = lane >> 5;
-        const int q = r >> 2, p = r & 3;                      // tr-read role of this lane inside its 16-lane group
-        // wave (grp, ky) = the three kx taps of row ky for ci blocks [cb0, cb0 + ncb)
-        const int ky = wave % 3;
-        const int cb0 = (wave / 3) * CB;
-        const int ncb = NCI - cb0 < CB ? NCI - cb0 : CB;
-        f32x16 acc[CB * 3];
+        const int q = r >> 2, p = r & 3;
+        f32x16 acc[CB * NT];
 #pragma unroll
-        for (int a = 0; a < CB * 3; ++a)
+        for (int a = 0; a < CB * NT; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
-        // A transposing read: lane (r = (q, p), hb) supplies the address of image row pix + q, columns 4p .. 4p+3 of a 16-channel
-        // block and receives channel r of that block for pixels pix .. pix + 3; two reads (pix, pix + 4) = the 8 k values
-        // 8h .. 8h + 7 of an operand.
-        // A wave of the last group may own fewer than CB blocks (NCI = 3, 5): it runs the MFMAs of a phantom block on block 0's
-        // fragments and never writes that accumulator - the K loop stays free of branches (with them the compiler's schedule is
-        // read - wait - MFMA per fragment, the LDS latency exposed 24 times per tile row).
-        unsigned abase[CB];                                   // byte offset of block cb's fragment for pixel 8h + q of a unit image
+        unsigned abase[CB], bbase[NT];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
             abase[cb] = (unsigned)((cb < ncb ? cb0 + cb : 0) * (WM_UPX * 64) + (8 * h + q) * 64 + hb * 32 + 8 * p);
-        const unsigned bbase = (unsigned)(YOFF + ((2 - ky) * WM_HW + 8 * h + q + 2) * 64 + hb * 32 + 8 * p);
-        auto tr2 = [&](const unsigned char* a, int stride4) -> bf16x8 {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {                        // dy pixel of x pixel (row, c) under tap (ky, kx): (row + 2 - ky, c + 2 - kx)
+            const int t = tap0 + j, ky = t / 3, kx = t - 3 * ky;
+            bbase[j] = (unsigned)(YOFF + ((2 - ky) * WM_HW + 2 - kx + 8 * h + q) * 64 + hb * 32 + 8 * p);
+        }
+        auto tr2 = [&](const unsigned char* a) -> bf16x8 {
             const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
-            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + stride4));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 256));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         // The four K steps (unit row rl, half kq) of a unit, unrolled; the fragments of step k + 1 are read before the MFMAs of
         // step k (pinned: the scheduler otherwise sinks every read to its first use) - ACROSS units too: the barrier that hands
         // unit u + 1 over sits in front of the last step's MFMAs of unit u, whose fragments are in registers by then (every read
-        // of unit u has been waited for), and the first fragments of unit u + 1 are read under those MFMAs.  This wave's share of
-        // the x staging (unit u + 1 into its slot, the loads of unit u + 3) goes behind the MFMAs of step 1.
-        bf16x8 a[2][CB], b[2][3];
+        // of unit u has been waited for), and the first fragments of unit u + 1 are read under those MFMAs.
+        bf16x8 a[2][CB], b[2][NT];
         auto load_step = [&](int u, int k, int buf) {
-            const unsigned char* xs = lds + (u & 1) * C::UBYTES;
-            const unsigned char* ys = lds + (u & 1) * WM_YBYTES;   // (+ bbase)
-            const int rl = k >> 1, kq = k & 1;
-            const int pxo = rl * TW + 16 * kq;                // first pixel of the K step (+ 8h + q per lane: in abase)
+            const unsigned char* xs = lds + (u & 1) * C::UBYTES + ((k >> 1) * TW + 16 * (k & 1)) * 64;
+            const unsigned char* ys = lds + (u & 1) * WM_YBYTES + ((k >> 1) * WM_HW + 16 * (k & 1)) * 64;
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) a[buf][cb] = tr2(xs + abase[cb] + pxo * 64, 256);
+            for (int cb = 0; cb < CB; ++cb) a[buf][cb] = tr2(xs + abase[cb]);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)                    // dy pixel of x pixel (row, c) under tap (ky, kx): (row + 2 - ky, c + 2 - kx)
-                b[buf][kx] = tr2(ys + bbase + (rl * WM_HW + 16 * kq - kx) * 64, 256);
+            for (int j = 0; j < NT; ++j) b[buf][j] = tr2(ys + bbase[j]);
         };
-        auto unit = [&](int u, XSet& xs) {                    // xs holds this wave's pieces of unit u + 1
+        auto unit = [&](int u, Set& st) {                     // st holds this wave's pieces of unit u + 2
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cur = k & 1;
@@ -331,33 +297,43 @@ __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_d
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
-                        acc[cb * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][cb], b[cur][kx], acc[cb * 3 + kx], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (k == 1 && u + 1 < U) {                    // (uniform)
-                    if (u + 2 < U) vm_wait<XPT>(); else vm_wait<0>();
-                    write_x(u + 1, xs);
-                    if (u + 3 < U) load_x(u + 3, xs);
-                }
+                        acc[cb * NT + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][cb], b[cur][j], acc[cb * NT + j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // Staging right behind the barrier's last MFMA batch, in EVERY wave at the same time: a memory instruction issued
+            // while the SIMD streams MFMAs costs its wave 100+ cycles (s_memtime stamps: ten of them 800 - 1400 cycles per
+            // wave and unit when placed in the middle of the unit, where the waves have drifted apart), so the eight waves' stores
+            // and loads go where no MFMA is in flight: unit u + 2 into the slot unit u was read from, then the loads of unit u + 4.
+            if (u + 2 < U) {                                  // (uniform)
+                stamp();
+                if (u + 3 < U) vm_wait<S>(); else vm_wait<0>();
+                stamp();
+                write(u + 2, st);
+                if (u + 4 < U) load(u + 4, st);
+                stamp();
+            }
         };
+        Set sa, sb;                                           // even / odd units
         if (U > 0) {
-            load_x(0, xa);
-            load_x(1, xb);
-            vm_wait<XPT>();
-            write_x(0, xa);
-            if (2 < U) load_x(2, xa);
+            load(0, sa);
+            load(1, sb);
+            vm_wait<S>();
+            write(0, sa);
+            if (2 < U) load(2, sa);
+            if (2 < U) vm_wait<S>(); else vm_wait<0>();
+            write(1, sb);
+            if (3 < U) load(3, sb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                     // barrier 0: unit 0 is in its slot
+            __builtin_amdgcn_s_barrier();                     // barrier 0: units 0 and 1 are in their slots
             load_step(0, 0, 0);
         }
 #pragma unroll 1
         for (int u = 0; u < U; u += 2) {
-            unit(u, xb);
-            unit(u + 1, xa);
+            unit(u, sa);
+            unit(u + 1, sb);
         }
         // ---- partial slabs [split][ci block][tap][ci 32][co 32] (the layout wgrad_reduce_kernel sums)
         // D[m][n]: n = co = lane & 31, m = ci = (e & 3) + 8 (e >> 2) + 4 h
@@ -365,31 +341,35 @@ __global__ __launch_bounds__(WM_NTHR, 2) void wgrad_m32_kernel(const nvq_wgrad_d
         for (int cb = 0; cb < CB; ++cb) {
             if (cb >= ncb) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float* part = d.workspace + ((size_t)(blockIdx.x * NCI + cb0 + cb) * 9 + ky * 3 + kx) * (WG_C * WG_C);
-                const f32x16 v = acc[cb * 3 + kx];
+            for (int j = 0; j < NT; ++j) {
+                float* part = d.workspace + ((size_t)(blockIdx.x * NCI + cb0 + cb) * 9 + tap0 + j) * (WG_C * WG_C);
+                const f32x16 v = acc[cb * NT + j];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) part[((e & 3) + 8 * (e >> 2) + 4 * h) * WG_C + (lane & 31)] = v[e];
             }
         }
-    }
-    // ---- bias partials bias_part[split][32]: the dy waves' sums (thread pt: channels 8 (pt & 3) .. + 7) meet in LDS
+    };
+    if (three) role(std::integral_constant<int, 3>{}, std::false_type{});
+    else role(std::integral_constant<int, 2>{}, std::true_type{});
+
+    // ---- bias partials bias_part[split][32]: the dy-staging threads' sums (thread dt: channels 8 (dt & 3) .. + 7) meet in LDS
     if (d.dbias != nullptr) {                                 // (uniform)
-        float* scratch = reinterpret_cast<float*>(lds);       // [128][8]
+        float* scratch = reinterpret_cast<float*>(lds);       // [384][8]
         __syncthreads();                                      // every wave is done with the LDS images
-        if (wave >= WM_NCONS) {
+        if (!three) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) scratch[8 * (tid - 64 * WM_NCONS) + e] = bsum[e];
+            for (int e = 0; e < 8; ++e) scratch[8 * dt + e] = bsum[e];
         }
         __syncthreads();
         if (tid < 32) {
             const int piece = tid >> 3, e = tid & 7;          // channel tid = 8 piece + e
             float sum = 0.f;
-            for (int k = piece; k < WM_PT; k += 4) sum += scratch[8 * k + e];
+            for (int k = piece; k < WM_DYT; k += 4) sum += scratch[8 * k + e];
             float* bp = d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C;
             bp[(size_t)blockIdx.x * WG_C + tid] = sum;
         }
     }
+    (void)dyw;
 }
 
 // ---------------------------------------------------------------- 1x1 (the blocks' local feature fusion, lff)

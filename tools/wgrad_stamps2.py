@@ -19,15 +19,12 @@ st = ws[OFF:OFF + 8 * 2048 * 2].cpu().numpy().view(np.uint64).reshape(8, 2048)
 t0 = st[st > 0].min()
 cons = (st[0] - t0).astype(np.int64)   # consumer wave 0: (before barrier, after barrier) per unit
 prod = (st[6] - t0).astype(np.int64)   # producer wave 6: (after vm_wait, after write, after load, after barrier) per iteration
-print("consumer waves: per unit, cycles from leaving barrier u to arriving at barrier u + 1 | wait at the barrier")
-for u in range(20, 30):
+print("per unit and wave: barrier -> staging start (last MFMA batch) | wait for loads | stores + loads | staging end -> next barrier (3 MFMA batches) | wait at barrier")
+for u in range(20, 28):
     row = []
-    for w in range(6):
+    for w in range(8):
         c = (st[w] - t0).astype(np.int64)
-        a, b = c[2 * u], c[2 * u + 1]
-        row.append(f"{a - c[2 * u - 1]:5d}|{b - a:5d}")
-    print(f"  unit {u}: " + "  ".join(row))
-print("producer wave 6: per iteration [vm_wait done, writes issued, loads issued, barrier left]")
-for i in range(20, 32):
-    w, x, y, z = prod[4 * i:4 * i + 4]
-    print(f"  it {i}: wait-done {w:8d}  write {x - w:6d}  load {y - x:6d}  barrier {z - y:6d}   vm_wait took {w - prod[4 * i - 1]:6d}")
+        b0, b1, s0, s1, s2 = c[5 * u: 5 * u + 5]      # unit u: [before barrier, after], [staging start, loads waited, staged]
+        nb0 = c[5 * u + 5]
+        row.append(f"{s0 - b1:5d}|{s1 - s0:4d}|{s2 - s1:4d}|{nb0 - s2:5d}|{b1 - b0:5d}")
+    print(f"  unit {u}: " + "   ".join(row))
