@@ -886,16 +886,20 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int ncz = (d.cout_store + NT - 1) / NT;
     const int nkc = (d.cin + KCB - 1) / KCB;
     int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
-    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them.  (Choosing the 8-row
-    // tiles of the 4-wave kernel for launches that leave the device under-filled gave 4.43 -> 4.23 ms on the 8-clip 64x64 step
-    // and was taken out again: the small parity tests would no longer run the kernel the 540p benchmark runs.)
+    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them AND the launch fills the
+    // device: with fewer than one 16-row workgroup per CU (the 8-clip 64x64 continual-learning step, the coarse levels of the
+    // recovery net) the 8-row tiles of the 4-wave kernel are chosen, twice the workgroups for the same work.  The two kernels
+    // give bit-identical results (tests/test_kernels_gpu.py::test_conv_bf16_eight_wave_kernels_equal_the_four_wave_ones), and
+    // tile_rows = 16 / 162 / 164 / 8 still force one form.
     // the same tile on v_mfma_f32_32x32x16_bf16 (conv_m32.hip): tile_rows 162 = two rows per wave (8 waves), 164 = four rows
     // per wave (4 waves).  Automatic for up to 128 input channels (profiles/r04_mfma32_per_shape.txt: the two-row form is 1 - 7 %
     // faster there and 0 - 4 % slower on 160 / 192; the four-row form loses everywhere); tile_rows 16 = always the 16x16x32 form.
+    const bool underfilled = (long)tilesX * ((d.h + 2 * TH - 1) / (2 * TH)) * d.n * ncz < NVQ_FILL_WORKGROUPS;
+    const int rows = d.tile_rows == 0 && underfilled ? 8 : d.tile_rows;
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && vec_ok &&
-        (d.tile_rows == 162 || d.tile_rows == 164 || (d.tile_rows == 0 && d.cin <= 128)))
-        return conv_forward_m32(d, d.tile_rows == 164 ? 4 : 2, g_debug_mode & 3, s);
-    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && d.tile_rows != 8) {
+        (rows == 162 || rows == 164 || (rows == 0 && d.cin <= 128)))
+        return conv_forward_m32(d, rows == 164 ? 4 : 2, g_debug_mode & 3, s);
+    if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && rows != 8) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);
         hipLaunchKernelGGL((conv_bf16_kernel<2, 3, true, 8>), grid8, dim3(512), 0, s, d, tilesX, tilesY, nkc, vec_ok,
@@ -971,6 +975,8 @@ int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, in
 int conv_wgrad_bf16(const nvq_wgrad_desc& d, int nsplit, int nci, int nco, int tilesX, int tilesY, int ntiles,
                     hipStream_t s) {
     if ((d.variant & 15) != 1 && wgrad_m32_takes(d)) return conv_wgrad_m32(d, s);
+    NVQ_REQUIRE((d.variant & 15) != 2, "conv_wgrad: variant 2 (all-input-channel kernel) does not take %d -> %d channels, ksize %d",
+                d.cin, d.cout, d.ksize);
     // nsplit / nci come from the caller in 32-ci units; with bf16 x and >= 64 input channels use 64-ci workgroups
     const bool wide = d.x_bf16 && d.dy_bf16 && d.cin_w >= 64;   // (the bf16-x / fp32-dy wide variant spills)
     const int ncig = wide ? (nci + 1) / 2 : nci;

@@ -555,6 +555,11 @@ bool wgrad_m32_takes(const nvq_wgrad_desc& d) {
     if ((size_t)(d.x_plane ? (size_t)nci * d.x_plane : (size_t)d.n * d.h * d.w * d.x_ld) >= ((size_t)1 << 32) ||
         (size_t)d.n * d.h * d.w * d.dy_ld >= ((size_t)1 << 31))
         return false;
+    // persistent workgroups, each leaving its own partial slabs: with fewer than four tiles per workgroup (the 64x64 clips of
+    // the continual-learning loop: 256 tiles) the prologue and the reduce over 256 / 512 slabs cost more than the kernel saves
+    // (4.19 -> 4.70 ms per step there), and the split kernel with its few pixel splits stays
+    const long ntiles = (long)((d.w + TW - 1) / TW) * ((d.h + WM_TR - 1) / WM_TR) * d.n;
+    if ((d.variant & 15) != 2 && ntiles < 4 * (d.ksize == 3 ? 256 : 512)) return false;
     // (3x3 with 64 input channels: equal in isolation, 15 % slower than the split kernel inside the training step)
     if (d.ksize == 3) return d.x_plane && d.cout == 32 && nci >= 3 && nci <= 6 && d.cin >= d.x_ld;
     // 1x1: 64 .. 256 input channels, 32 / 64 output channels; slice-planar or interleaved x

@@ -110,7 +110,8 @@ typedef struct nvq_conv_desc {
     unsigned in_plane;
     /* Kernel-variant hint, results do not depend on it (beyond the fp32 summation order inside a 32-channel K chunk): 0 =
      * automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their 8x32-pixel, four-wave form (the automatic choice for bf16 input is
-     * an eight-wave form: 16x32 tiles for cout <= 32, two 32-channel halves per workgroup for cout >= 64); for cout <= 32 also
+     * an eight-wave form: 16x32 tiles for cout <= 32 - unless that gives fewer than 256 workgroups, then the 8x32 form -, two
+     * 32-channel halves per workgroup for cout >= 64); for cout <= 32 also
      * 16 = the 16x32-tile kernel on v_mfma_f32_16x16x32_bf16, 162 / 164 = the same tile on v_mfma_f32_32x32x16_bf16 with two /
      * four tile rows per wave (automatic: 162 up to 128 input channels, 16 above).  Lets a caller A/B the forms without any
      * library state. */
@@ -156,8 +157,10 @@ typedef struct nvq_wgrad_desc {
     int x_bf16, dy_bf16;                /* storage type of x / dy (see nvq_conv_desc); need NVQ_MATH_BF16 */
     unsigned x_plane;                   /* slice-planar x (see nvq_conv_desc::in_plane; bf16 x, x_coff == 0); 0 = interleaved */
     /* Kernel-variant hint, results do not depend on it (up to the summation order): 0 = automatic; 1 = always the
-     * (pixel split, ci chunk, co chunk) kernels, never the all-input-channel kernel (3x3, cout = 32, slice-planar bf16 x,
-     * bf16 dy, cin in {64, .., 192}: x read without halo and dy once per launch).  Lets a caller A/B the two forms. */
+     * (pixel split, ci chunk, co chunk) kernels; 2 = always the all-input-channel kernels (an error for a shape they do not
+     * take).  The all-input-channel kernels (bf16 x and dy; 3x3: cout = 32, slice-planar x, cin in {96, .., 192}; 1x1: cin in
+     * {64, .., 256}, cout <= 64) read x without halo and dy once per launch, as persistent workgroups; automatic from four
+     * 4x32-pixel tiles per workgroup on (smaller launches: the split kernels).  Lets a caller A/B the two forms. */
     int variant;
 } nvq_wgrad_desc;
 size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */

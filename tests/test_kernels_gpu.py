@@ -694,7 +694,8 @@ def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
 def test_conv_bf16_weight_gradient_all_input_channels(K, Fc, cin, N, H, W):
     """nvq_conv_wgrad on a slice-planar bf16 dense-block buffer, 3x3, cout = 32: the all-input-channel kernel (wgrad_m32.hip: x
     units without halo, dy with halo, six MFMA waves + two dy waves, persistent over tiles) against autograd's weight / bias
-    gradient of F.conv2d on the same bf16 values, and against the (pixel split, ci chunk) kernel (variant = 1).  Sizes with
+    gradient of F.conv2d on the same bf16 values, and against the (pixel split, ci chunk) kernel (variant = 1; 2 forces the
+    all-input-channel kernel, which the automatic choice takes from 1024 tiles on).  Sizes with
     partial tiles in both directions, one to many tiles per workgroup, leading tensors of 32 / 64 / 128 channels, alpha and
     accumulate."""
     x, dy = bf(rnd(N, cin, H, W)), bf(rnd(N, 32, H, W, seed=3))
@@ -708,14 +709,14 @@ def test_conv_bf16_weight_gradient_all_input_channels(K, Fc, cin, N, H, W):
     ds = to_nhwc_bf16(dy, 40, 8)
     ws = ws_tensor(K)
     outs = []
-    for variant in (0, 1):
+    for variant in (2, 1):
         dw, db = torch.full((32, cin, 3, 3), 7.0, device="cuda"), torch.full((32,), 7.0, device="cuda")
         K.conv_wgrad(cat.inp(cin), cin, K.Sl(ds, 32, 8), dw, db, ws, 3, math=K.MATH_BF16, variant=variant)
         outs.append((dw, db))
     assert rel(outs[0][0], w.grad) < TOL and rel(outs[0][1], dy.sum((0, 2, 3))) < TOL
     assert rel(outs[0][0], outs[1][0]) < TOL and rel(outs[0][1], outs[1][1]) < TOL
     dw, db = outs[0][0].clone(), outs[0][1].clone()
-    K.conv_wgrad(cat.inp(cin), cin, K.Sl(ds, 32, 8), dw, db, ws, 3, alpha=0.5, accumulate=True, math=K.MATH_BF16)
+    K.conv_wgrad(cat.inp(cin), cin, K.Sl(ds, 32, 8), dw, db, ws, 3, alpha=0.5, accumulate=True, math=K.MATH_BF16, variant=2)
     assert rel(dw, 1.5 * w.grad) < TOL and rel(db, 1.5 * dy.sum((0, 2, 3))) < TOL
 
 
@@ -1093,12 +1094,12 @@ def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
             K.conv_forward(buf.inp(cin), wp, b3.cuda(), buf.y(i), 3, relu=True, math=K.MATH_BF16, bits=bt, bits_mode=1)
         assert torch.equal(inter.t[..., cin:cin + 32], plan.slices[i]) and torch.equal(bits[0], bits[1])
         dws = []
-        for buf, variant in ((inter, 0), (plan, 1), (plan, 0)):   # weight gradient of the same layer: x = the prefix
+        for buf, variant in ((inter, 0), (plan, 1), (plan, 2 if cin >= 96 else 0)):   # weight gradient of the same layer
             dw, db = torch.empty(32, cin, 3, 3, device="cuda"), torch.empty(32, device="cuda")
             K.conv_wgrad(buf.inp(cin), cin, buf.y(4), dw, db, ws, 3, math=K.MATH_BF16, variant=variant)
             dws.append((dw, db))
         assert torch.equal(dws[0][0], dws[1][0]) and torch.equal(dws[0][1], dws[1][1])   # the same kernel on either layout
-        # variant 0 on the slice-planar buffer is the all-input-channel kernel (wgrad_m32.hip): other fp32 summation order
+        # variant 2 on the slice-planar buffer is the all-input-channel kernel (wgrad_m32.hip): other fp32 summation order
         assert rel(dws[2][0], dws[1][0]) < TOL and rel(dws[2][1], dws[1][1]) < TOL
     # 1x1 over all channels (lff) with residual x, 64-channel output into the next block's x; its weight gradient
     wl, bl = rnd(Fc, CAT, 1, 1, scale=0.1, seed=7), rnd(Fc, seed=8)
@@ -1110,8 +1111,12 @@ def test_slice_planar_dense_block_buffer(K, Fc, N, H, W):
     dws = []
     for buf, nb in zip((inter, plan), nxt):
         dw, db = torch.empty(Fc, CAT, 1, 1, device="cuda"), torch.empty(Fc, device="cuda")
-        K.conv_wgrad(buf.inp(CAT), CAT, nb.x(), dw, db, ws, 1, alpha=0.2, math=K.MATH_BF16)
+        K.conv_wgrad(buf.inp(CAT), CAT, nb.x(), dw, db, ws, 1, alpha=0.2, math=K.MATH_BF16, variant=1)
         dws.append(dw)
+        if CAT % 32 == 0 and Fc % 32 == 0 and 64 <= CAT <= 256 and Fc <= 64:   # the all-input-channel 1x1 kernel, either layout
+            dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+            K.conv_wgrad(buf.inp(CAT), CAT, nb.x(), dw2, db2, ws, 1, alpha=0.2, math=K.MATH_BF16, variant=2)
+            assert rel(dw2, dw) < TOL and rel(db2, db) < TOL
     assert torch.equal(dws[0], dws[1])
     # 3x3 over all channels -> 64 (the block-input gradient conv) with the centre-tap hint
     wx = rnd(Fc, CAT, 3, 3, scale=0.1, seed=9)

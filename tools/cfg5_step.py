@@ -10,8 +10,14 @@ from nerve_cl.continual import EWC
 from nerve_cl.models import EnhancementConfig, EnhancementEngine
 
 dev = torch.device("cuda", 0)
-for precision, graphs in (("bf16", "auto"), ("bf16", "off"), ("fp32", "auto"), ("fp32", "off")):
-    for batch in (8, 16):
+MODES = (("bf16", "auto"), ("bf16", "off"), ("fp32", "auto"), ("fp32", "off"))
+if os.environ.get("CFG5_ONLY"):            # e.g. CFG5_ONLY=bf16,auto,8 under rocprofv3
+    _p, _g, _b = os.environ["CFG5_ONLY"].split(",")
+    MODES, BATCHES = ((_p, _g),), (int(_b),)
+else:
+    BATCHES = (8, 16)
+for precision, graphs in MODES:
+    for batch in BATCHES:
         torch.manual_seed(0)
         model = EnhancementEngine(EnhancementConfig(frame_recovery_enabled=False, super_resolution_enabled=True)).to(dev)
         TC.configure_precision(model, precision, graphs)
