@@ -16,6 +16,14 @@ def label_of(kernel_name: str):
         # bench.py's label counts (the channel-split 64-channel kernel is <2, 3, true, 8, 2> = label <4,3>)
         nb = int(m.group(2)) * (int(m.group(5)) if m.group(5) else 1)
         return f"{m.group(1)}<{nb},{m.group(3)}>"
+    # the 32x32x16-MFMA forms of the same launches (conv_m32.hip, wgrad_m32.hip) carry the label of the descriptor they serve:
+    # conv_m32_kernel = 3x3, cout <= 32; wgrad_m32_kernel = 3x3 all-input-channel; wgrad1_m32_kernel = 1x1
+    if "conv_m32_kernel<" in kernel_name:
+        return "conv_bf16_kernel<2,3>"
+    if "wgrad1_m32_kernel<" in kernel_name:
+        return "wgrad_bf16_kernel<1>"
+    if "wgrad_m32_kernel<" in kernel_name:
+        return "wgrad_bf16_kernel<3>"
     m = re.search(r"(wgrad_bf16_kernel|wgrad_f32_kernel)<(\d+)", kernel_name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
