@@ -635,6 +635,282 @@ __global__ __launch_bounds__(256, 2) void rdb_tail_kernel(const nvq_conv_desc d3
     conv_epilogue<NBL, true>(dl, lacc, n, ty, tx, 0, wave, c, g, vecl);
 }
 
+// The same tile as eight waves with two roles (the automatic choice): waves 0-3 are the 3x3 layer's waves of the kernel above
+// (two tile rows each, 72 MFMAs per chunk) and stage only the 3x3 weights; waves 4-7 own the lff accumulators (64 channels x
+// the same two rows each, 16 MFMAs per chunk on the centre pixels), stage the halo tile and the lff weights, and write the
+// lff output.  With the 64 lff accumulators in the same waves as the 3x3's the kernel above needs ~190 VGPRs, i.e. two waves
+// per SIMD, each of which also issues 12 loads + 12 LDS stores per chunk beside its MFMAs; split like this both roles fit 128
+// registers (four waves per SIMD) and the 3x3 waves' instruction stream is fragment reads and MFMAs only.
+__global__ __launch_bounds__(512, 4) void rdb_tail8_kernel(const nvq_conv_desc d3, const nvq_conv_desc dl, int tilesX,
+                                                           int tilesY, int nkc, int vec3, int vecl) {
+    // libnvq_debug.so only (tools/rdb_tail_ab.py): tile_rows >> 8 = 1 no 3x3 MFMAs, 2 no lff MFMAs, 4 fetch once, 8 no LDS stores,
+    // 16 no lff stores, 32 no y4 epilogue, 64 no first fetch, 128 no residual loads; the shipped library's dbg is the literal 0
+#ifdef NVQ_DEBUG_TOOLS
+    const int dbg = d3.tile_rows >> 8;
+#else
+    constexpr int dbg = 0;
+#endif
+    constexpr int NB = 2, NT = 32, KS = 3, TAPS = 9, NBL = 4, NTL = 64;
+    constexpr int HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;
+    constexpr int WS3 = ws_stride_halfs(TAPS, NT);            // 10240 halfs
+    constexpr int WSL = ws_stride_halfs(1, NTL);              // 2048 halfs
+    constexpr int XITEMS = NPIX * 4;
+    constexpr int XPER = XITEMS / 256;                        // 5 (lff waves); the last XITEMS - 1280 = 80 pieces: 3x3 waves
+    constexpr int XREST = XITEMS - XPER * 256;
+    static_assert(XREST >= 0 && XREST <= 256, "one leftover halo piece per 3x3-wave thread at most");
+    constexpr int WPER = WS3 / 8 / 256;                       // 5 (3x3 waves)
+    constexpr int T4S = 40;
+    static_assert(WSL / 8 == 256 && T4S == STAGE_PX && TH * TW * T4S <= WS3, "see rdb_tail_kernel");
+    static_assert(2 * TW * STAGE_PX64 * 4 <= NPIX * XSB + WS3, "lff staging tiles fit the LDS stages");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XSB + WS3 + WSL];
+    __bf16* xs = lds;
+    __bf16* ws = lds + NPIX * XSB;
+    __bf16* wl = ws + WS3;
+
+    const int tid = threadIdx.x;
+    const int rtid = tid & 255;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lffw = wave >= 4;                              // (wave-uniform)
+    const int w4 = wave & 3;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int H = d3.h, W = d3.w;
+    const u32x4* w3p = reinterpret_cast<const u32x4*>(d3.wpack);
+    const u32x4* wlp = reinterpret_cast<const u32x4*>(dl.wpack);
+    const __bf16* in16 = reinterpret_cast<const __bf16*>(d3.in) + d3.in_coff;
+    auto ldP = [&](int rr, int xh, int dx) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(xs + ((2 * w4 + rr) * HW_ + xh * 16 + c + dx) * XSB + 8 * g);
+    };
+
+    const int nk0 = d3.in_plane ? d3.in_ld >> 5 : 0x7fffffff;  // slice-planar input: see conv_bf16_kernel
+    const int sh0 = d3.in_plane ? __ffs(d3.in_ld >> 5) - 1 : 0;
+    const unsigned chg = 8 * (rtid & 3);
+    auto halo_off = [&](int item, bool& ok) -> unsigned {     // element offset of halo piece `item`'s pixel (0 and !ok outside)
+        const int hp = item >> 2;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+        ok = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        return ok ? (unsigned)(((size_t)(n * H + gy) * W + gx) * (d3.in_plane ? 32 : d3.in_ld)) : 0u;
+    };
+    auto chunk_off = [&](int kc, int& sh) -> unsigned {       // channel offset of chunk kc, shift of the pixel offsets
+        const bool lead = kc < nk0;
+        sh = lead ? sh0 : 0;
+        return (lead ? (unsigned)kc * KCB : (unsigned)kc * d3.in_plane) + chg;
+    };
+    if (!lffw) {
+        // ------------------------------------------------------------ 3x3 waves
+        f32x4 acc[NB][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < NB; ++a) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 wr[WPER], lr, xr5;
+        bool xok5;
+        const unsigned xoff5 = halo_off(XPER * 256 + rtid, xok5);
+        auto fetch = [&](int kc) {                            // the chunk's 3x3 and lff weights, the last 80 halo pieces
+#pragma unroll
+            for (int k = 0; k < WPER; ++k) wr[k] = w3p[(size_t)kc * (WS3 / 8) + rtid + k * 256];
+            lr = wlp[(size_t)kc * (WSL / 8) + rtid];
+            int sh;
+            const unsigned o0 = chunk_off(kc, sh);
+            if (rtid < XREST) xr5 = *reinterpret_cast<const u32x4*>(in16 + ((xoff5 << sh) + o0));
+        };
+        auto ldW = [&](int tap, int cb) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(ws + ((tap * 4 + g) * NT + cb * 16 + c) * 8);
+        };
+        if (!(dbg & 64)) fetch(0);
+        for (int kc = 0; kc < nkc; ++kc) {
+            __syncthreads();
+            if (!(dbg & 8)) {
+#pragma unroll
+            for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[rtid + k * 256] = wr[k];
+            reinterpret_cast<u32x4*>(wl)[rtid] = lr;
+            if (rtid < XREST) {
+                const int item = XPER * 256 + rtid;
+                *reinterpret_cast<u32x4*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = xok5 ? xr5 : (u32x4){0u, 0u, 0u, 0u};
+            } }
+            __syncthreads();
+            if (!(dbg & 4)) { if (kc + 1 < nkc) fetch(kc + 1);
+            else lr = wlp[(size_t)nkc * (WSL / 8) + rtid]; }   // lff weights of the y4 channels
+            if (dbg & 1) continue;
+            bf16x8 lo[2], hi[2], wa[NB], wn[NB];
+            lo[0] = ldP(0, 0, 0); lo[1] = ldP(0, 1, 0);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) wa[cb] = ldW(0, cb);
+            hi[0] = ldP(1, 0, 0); hi[1] = ldP(1, 1, 0);
+#pragma unroll
+            for (int s = 0; s < TAPS; ++s) {                  // dx-major, dy-minor (see conv_bf16_kernel)
+                const int dy = s % KS;
+                const bool last = s + 1 == TAPS;
+                const int ndx = (s + 1) / KS, ndy = (s + 1) % KS;
+                const bool same_dx = !last && ndy != 0;
+                bf16x8 nlo[2], nhi[2];
+                if (!last) {
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) wn[cb] = ldW(ndy * KS + ndx, cb);
+                }
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb)
+                        acc[cb][xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], lo[xh], acc[cb][xh], 0, 0, 0);
+                    if (same_dx) nhi[xh] = ldP(dy + 2, xh, ndx);
+                    else if (!last) nlo[xh] = ldP(0, xh, ndx);
+                }
+#pragma unroll
+                for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb)
+                        acc[cb][2 + xh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb], hi[xh], acc[cb][2 + xh], 0, 0, 0);
+                    if (same_dx) nlo[xh] = hi[xh];
+                    else if (!last) nhi[xh] = ldP(1, xh, ndx);
+                }
+                if (!last) {
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) { lo[xh] = nlo[xh]; hi[xh] = nhi[xh]; }
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) wa[cb] = wn[cb];
+                }
+            }
+        }
+        // y4 = relu(acc + bias) as bf16 into the wave's rows of the y4 tile (bias, ReLU, bit masks: the regular epilogue)
+        __syncthreads();                                      // every wave is done with xs / ws / wl
+        reinterpret_cast<u32x4*>(wl)[rtid] = lr;              // lff weights of channels [cin, cin + 32)
+        __bf16* t4 = ws;
+        if (!(dbg & 32)) conv_epilogue<NB>(d3, acc, n, ty, tx, 0, w4, c, g, vec3, TH, t4 + w4 * (2 * TW * T4S));
+        __syncthreads();                                      // the lff waves read the y4 tile
+        if (!(dbg & 32)) {   // y4 to the concat buffer as whole 64-byte pixel rows
+            __bf16* o16 = reinterpret_cast<__bf16*>(d3.out);
+            const __bf16* stage = t4 + w4 * (2 * TW * T4S);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int item = lane + k * 64;
+                const int px = item >> 2, piece = item & 3;
+                const int gy = ty * TH + 2 * w4 + (px >> 5), gx = tx * TW + (px & 31);
+                if (gy < H && gx < W)
+                    *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * d3.out_ld + d3.out_coff + 8 * piece) =
+                        *reinterpret_cast<const u32x4*>(stage + px * T4S + 8 * piece);
+            }
+        }
+        __syncthreads();                                      // the lff waves reuse the stages for their output
+        return;
+    }
+    // ---------------------------------------------------------------- lff waves
+    f32x4 lacc[NBL][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < NBL; ++a) lacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned xoff[XPER];
+    bool xok[XPER];
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) xoff[k] = halo_off(rtid + k * 256, xok[k]);
+    u32x4 xr[XPER];
+    auto fetch = [&](int kc) {
+        int sh;
+        const unsigned o0 = chunk_off(kc, sh);
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
+    };
+    auto ldL = [&](int cb) -> bf16x8 {                       // lff weights: m = cout cb*16 + c, k = channel 8g..
+        return *reinterpret_cast<const bf16x8*>(wl + (g * NTL + cb * 16 + c) * 8);
+    };
+    if (!(dbg & 64)) fetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        if (!(dbg & 8)) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < XPER; ++k) {
+                const int item = rtid + k * 256;
+                *reinterpret_cast<u32x4*>(xs + (item >> 2) * XSB + 8 * (item & 3)) = xok[k] ? xr[k] : z;
+            }
+        }
+        __syncthreads();
+        if (kc + 1 < nkc && !(dbg & 4)) fetch(kc + 1);
+        if (dbg & 2) continue;
+        bf16x8 px[4];                                         // the tile's own pixels: halo rows 2*w4 + 1 / + 2, dx = 1
+        px[0] = ldP(1, 0, 1); px[1] = ldP(1, 1, 1); px[2] = ldP(2, 0, 1); px[3] = ldP(2, 1, 1);
+#pragma unroll
+        for (int cb = 0; cb < NBL; ++cb) {
+            const bf16x8 wf = ldL(cb);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+                lacc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, px[pb], lacc[cb][pb], 0, 0, 0);
+        }
+    }
+    // Epilogue operands (the host side sends only lff descriptors with bias, a bf16 residual over all 64 channels and bf16
+    // output here): every load is issued here, before the barriers and the y4 step, so that the tile's tail is one memory round trip and not one per (pixel
+    // block, channel block) - with the generic epilogue's per-block loads the tail was 60 % of this kernel's time.
+    bool okp[4];
+    uint2 rr[4][NBL];
+    float4 bb[NBL];
+    const __bf16* r16 = reinterpret_cast<const __bf16*>(dl.res) + dl.res_coff + 4 * g;
+    auto res_load = [&](int pb) {
+        const int gy = ty * TH + 2 * w4 + (pb >> 1), gx = tx * TW + (pb & 1) * 16 + c;
+        okp[pb] = gy < H && gx < W;
+        const size_t pix = okp[pb] ? (size_t)(n * H + gy) * W + gx : 0;
+#pragma unroll
+        for (int cb = 0; cb < NBL; ++cb) rr[pb][cb] = *reinterpret_cast<const uint2*>(r16 + pix * dl.res_ld + cb * 16);
+    };
+    if (!(dbg & 128)) { res_load(0); res_load(1); res_load(2); res_load(3); }
+    __syncthreads();                                          // every wave is done with xs / ws / wl
+    __syncthreads();                                          // the y4 tile and the last lff weights (3x3 waves) are in LDS
+    {
+        const __bf16* t4 = ws;
+#pragma unroll
+        for (int cb = 0; cb < NBL; ++cb) {
+            const bf16x8 wf = ldL(cb);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int px = (2 * w4 + (pb >> 1)) * TW + (pb & 1) * 16 + c;
+                const bf16x8 yf = *reinterpret_cast<const bf16x8*>(t4 + px * T4S + 8 * g);
+                lacc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, yf, lacc[cb][pb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NBL; ++cb) bb[cb] = ld4(dl.bias + cb * 16 + 4 * g);   // (cache hits, under the barrier)
+    __syncthreads();                                      // every wave is done with t4 / wl
+    __bf16* stage = lds + w4 * (2 * TW * STAGE_PX64);
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        if (!okp[pb]) continue;
+#pragma unroll
+        for (int cb = 0; cb < NBL; ++cb) {                // the generic epilogue's arithmetic, in its order
+            float v[4] = {lacc[cb][pb][0] + bb[cb].x, lacc[cb][pb][1] + bb[cb].y, lacc[cb][pb][2] + bb[cb].z,
+                          lacc[cb][pb][3] + bb[cb].w};
+            {   // product and sum rounded separately, as in the generic epilogue (whose conditional add is not contracted)
+#pragma clang fp contract(off)
+                v[0] = v[0] * dl.alpha + __uint_as_float(rr[pb][cb].x << 16);
+                v[1] = v[1] * dl.alpha + __uint_as_float(rr[pb][cb].x & 0xffff0000u);
+                v[2] = v[2] * dl.alpha + __uint_as_float(rr[pb][cb].y << 16);
+                v[3] = v[3] * dl.alpha + __uint_as_float(rr[pb][cb].y & 0xffff0000u);
+            }
+            *reinterpret_cast<bf16x4*>(stage + ((pb >> 1) * TW + (pb & 1) * 16 + c) * STAGE_PX64 + cb * 16 + 4 * g) =
+                (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (dbg & 16) return;
+    __bf16* o16 = reinterpret_cast<__bf16*>(dl.out);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int item = lane + k * 64;
+        const int px = item >> 3, piece = item & 7;
+        const int gy = ty * TH + 2 * w4 + (px >> 5), gx = tx * TW + (px & 31);
+        if (gy < H && gx < W)
+            *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gx) * dl.out_ld + dl.out_coff + 8 * piece) =
+                *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX64 + 8 * piece);
+    }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // grid = (pixel split, ci chunk, 32-co chunk); K = the 32 pixels of one tile row per MFMA.  The LDS images stay
 // [pixel][channels]; ds_read_b64_tr_b16 delivers, per 16-lane group, 4 pixels x 16 channels transposed, i.e.
@@ -886,15 +1162,16 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int ncz = (d.cout_store + NT - 1) / NT;
     const int nkc = (d.cin + KCB - 1) / KCB;
     int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + TH - 1) / TH;
-    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them AND the launch fills the
-    // device: with fewer than one 16-row workgroup per CU (the 8-clip 64x64 continual-learning step, the coarse levels of the
-    // recovery net) the 8-row tiles of the 4-wave kernel are chosen, twice the workgroups for the same work.  The two kernels
-    // give bit-identical results (tests/test_kernels_gpu.py::test_conv_bf16_eight_wave_kernels_equal_the_four_wave_ones), and
-    // tile_rows = 16 / 162 / 164 / 8 still force one form.
+    // 16-row tiles (8 waves) for the cout <= 32 3x3 kernel with bf16 input, when the image fills them AND is large enough for
+    // such launches to fill the device: images of fewer than NVQ_SMALL_IMAGE_TILES 16x32 tiles (the 64x64 clips of the
+    // continual-learning step, the coarse levels of the recovery net) take the 8-row tiles of the 4-wave kernel, twice the
+    // workgroups for the same work.  The rule looks at ONE image, not at the batch: the forms differ in their fp32 summation
+    // order inside a K chunk (32x32x16 vs 16x16x32 MFMA), and an image's result must not depend on how many others share the
+    // launch (tests/test_full_size_gpu.py, batch independence).  tile_rows = 16 / 162 / 164 / 8 still force one form.
     // the same tile on v_mfma_f32_32x32x16_bf16 (conv_m32.hip): tile_rows 162 = two rows per wave (8 waves), 164 = four rows
     // per wave (4 waves).  Automatic for up to 128 input channels (profiles/r04_mfma32_per_shape.txt: the two-row form is 1 - 7 %
     // faster there and 0 - 4 % slower on 160 / 192; the four-row form loses everywhere); tile_rows 16 = always the 16x16x32 form.
-    const bool underfilled = (long)tilesX * ((d.h + 2 * TH - 1) / (2 * TH)) * d.n * ncz < NVQ_FILL_WORKGROUPS;
+    const bool underfilled = tilesX * ((d.h + 2 * TH - 1) / (2 * TH)) < NVQ_SMALL_IMAGE_TILES;
     const int rows = d.tile_rows == 0 && underfilled ? 8 : d.tile_rows;
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && vec_ok &&
         (rows == 162 || rows == 164 || (rows == 0 && d.cin <= 128)))
@@ -967,8 +1244,15 @@ int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, in
     NVQ_REQUIRE((size_t)d3.n * d3.h * d3.w * d3.in_ld < ((size_t)1 << 32), "rdb_tail_forward: tensor exceeds 32-bit offsets");
     const int tilesX = (d3.w + TW - 1) / TW, tilesY = (d3.h + TH - 1) / TH;
     const int nkc = d3.cin / KCB;
-    hipLaunchKernelGGL(rdb_tail_kernel, dim3((unsigned)((long)tilesX * tilesY * d3.n)), dim3(256), 0, s, d3, dl, tilesX,
-                       tilesY, nkc, vec3, vecl);
+    // d3.tile_rows = 4, or an lff epilogue other than the dense block's (bias, bf16 residual over all channels, bf16 output):
+    // the four-wave kernel; otherwise the eight-wave, two-role one (same tiles, same results)
+    const bool usual = dl.out_bf16 && dl.bias && dl.res && dl.res_bf16 && dl.res_cmax >= 64 && !dl.out2 && !dl.relu && vecl;
+    if ((d3.tile_rows & 255) == 4 || !usual)
+        hipLaunchKernelGGL(rdb_tail_kernel, dim3((unsigned)((long)tilesX * tilesY * d3.n)), dim3(256), 0, s, d3, dl, tilesX,
+                           tilesY, nkc, vec3, vecl);
+    else
+        hipLaunchKernelGGL(rdb_tail8_kernel, dim3((unsigned)((long)tilesX * tilesY * d3.n)), dim3(512), 0, s, d3, dl, tilesX,
+                           tilesY, nkc, vec3, vecl);
     return check_launch("rdb_tail_forward");
 }
 

@@ -6,7 +6,7 @@ namespace nvq {
 
 constexpr int TH = 8;      // tile rows
 constexpr int TW = 32;     // tile cols
-constexpr int NVQ_FILL_WORKGROUPS = 256;   // one workgroup per CU: launches below this take the smaller tile form
+constexpr int NVQ_SMALL_IMAGE_TILES = 32;  // images of fewer 16x32-pixel tiles take the 8x32-tile conv form (conv_bf16.hip)
 constexpr int WG_C = 32;   // wgrad: channels per ci / co chunk
 constexpr int WGRAD_MAX_WG = 512;      // workgroups per wgrad launch (2 per CU)
 constexpr int WGRAD_MAX_SLABS = 1536;  // partial slabs (split x 32-ci chunk x 32-co chunk) the workspace holds (256 x 6)

@@ -31,6 +31,8 @@ _ws_cache: Dict[torch.device, torch.Tensor] = {}
 # When set to a dict, backward() stores intermediate gradients in it (tests / debugging only).
 DEBUG_CAPTURE: Optional[dict] = None
 
+_TAIL_ROWS = int(os.environ.get("NVQ_TAIL_ROWS", "0"))   # 4: the four-wave rdb_tail kernel (A/B switch, same results)
+
 
 def _fused_tail_ok(math: int, x: torch.Tensor, Cimg: int, scale: int) -> bool:
     """nvq_upsampler_tail_forward's domain: bf16 MFMA mode, a bf16-stored input, scale 2..4 with Cimg * scale^2 <= 16 / 32 / 64.
@@ -310,7 +312,7 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
             w3 = packs.get(f"residual_blocks.{k}.layers.{i}.0.weight", False, cin)
             K.rdb_tail_forward(cat.inp(cin), w3, P[f"residual_blocks.{k}.layers.{i}.0.bias"], cat.y(i), wl,
                                P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), alpha=0.2, res=cat.x(),
-                               bits=sv.bits[k][i] if use_bits else None)
+                               bits=sv.bits[k][i] if use_bits else None, tile_rows=_TAIL_ROWS)
         else:
             K.conv_forward(cat.inp(g.CAT), wl, P[f"residual_blocks.{k}.lff.bias"], xloc(k + 1), 1, alpha=0.2,
                            res=cat.x(), math=math)

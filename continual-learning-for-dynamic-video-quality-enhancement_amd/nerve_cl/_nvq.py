@@ -481,12 +481,14 @@ def conv_forward(x: Sl, wpack: torch.Tensor, bias: Optional[torch.Tensor], out: 
 
 
 def rdb_tail_forward(x: Sl, w3: torch.Tensor, b3, y4: Sl, wl: torch.Tensor, bl, out: Sl, *, alpha: float, res: Sl,
-                     bits: Optional[torch.Tensor] = None) -> None:
+                     bits: Optional[torch.Tensor] = None, tile_rows: int = 0) -> None:
     """Last dense layer (3x3, x -> y4 = the next 32 channels of the same buffer, bias + ReLU) and the block's 1x1 fusion
-    over [x | y4] (-> out = alpha * (lff + bias) + res) in one launch (nvq_rdb_tail_forward)."""
+    over [x | y4] (-> out = alpha * (lff + bias) + res) in one launch (nvq_rdb_tail_forward).  tile_rows = 4: the four-wave
+    kernel instead of the eight-wave, two-role one (same results)."""
     n, h, w, _ = x.t.shape
     ev0 = TIMER.start() if TIMER is not None else None
-    d3 = _conv_desc(x, w3, b3, y4, 3, relu=True, math=MATH_BF16, bits=bits, bits_mode=1 if bits is not None else 0)
+    d3 = _conv_desc(x, w3, b3, y4, 3, relu=True, math=MATH_BF16, bits=bits, bits_mode=1 if bits is not None else 0,
+                    tile_rows=tile_rows)
     xl = Sl(x.t, x.c + y4.c, x.coff, plane=x.plane)
     dl = _conv_desc(xl, wl, bl, out, 1, alpha=alpha, res=res, math=MATH_BF16)
     check(lib().nvq_rdb_tail_forward(C.byref(d3), C.byref(dl), stream()), "nvq_rdb_tail_forward")

@@ -110,7 +110,7 @@ typedef struct nvq_conv_desc {
     unsigned in_plane;
     /* Kernel-variant hint, results do not depend on it (beyond the fp32 summation order inside a 32-channel K chunk): 0 =
      * automatic; 8 = the 3x3 NVQ_MATH_BF16 kernels use their 8x32-pixel, four-wave form (the automatic choice for bf16 input is
-     * an eight-wave form: 16x32 tiles for cout <= 32 - unless that gives fewer than 256 workgroups, then the 8x32 form -, two
+     * an eight-wave form: 16x32 tiles for cout <= 32 - for images of fewer than 32 such tiles the 8x32 form -, two
      * 32-channel halves per workgroup for cout >= 64); for cout <= 32 also
      * 16 = the 16x32-tile kernel on v_mfma_f32_16x16x32_bf16, 162 / 164 = the same tile on v_mfma_f32_32x32x16_bf16 with two /
      * four tile rows per wave (automatic: 162 up to 128 input channels, 16 above).  Lets a caller A/B the forms without any

@@ -1477,7 +1477,7 @@ def test_head_gradient_through_matrix_core_wgrad(K):
     assert rel(dw, w.grad) < TOL and rel(db, b.grad) < TOL
 
 
-@pytest.mark.parametrize("N,H,W,out16", [(2, 19, 37, True), (1, 8, 64, False)])
+@pytest.mark.parametrize("N,H,W,out16", [(2, 19, 37, True), (1, 8, 64, False), (3, 41, 70, True)])
 def test_rdb_tail_forward_fused(K, N, H, W, out16):
     """nvq_rdb_tail_forward = last dense 3x3 layer (in place, + bit masks) followed by the 1x1 lff with 0.2 scaling and
     residual: same results as the two separate launches."""
@@ -1498,6 +1498,11 @@ def test_rdb_tail_forward_fused(K, N, H, W, out16):
     K.rdb_tail_forward(K.Sl(b, cin, 0), w3p, b3.cuda(), K.Sl(b, 32, cin), wlp, bl.cuda(), K.Sl(ob, Fc, 0), alpha=0.2,
                        res=K.Sl(b, Fc, 0), bits=bits_b)
     assert torch.equal(a, b) and torch.equal(bits_a, bits_b)
+    # the four-wave kernel (tile_rows = 4) and the eight-wave, two-role one (automatic): the same sums in the same order
+    b4, ob4, bits_4 = to_nhwc_bf16(cat), torch.zeros_like(oa), torch.zeros_like(bits_a)
+    K.rdb_tail_forward(K.Sl(b4, cin, 0), w3p, b3.cuda(), K.Sl(b4, 32, cin), wlp, bl.cuda(), K.Sl(ob4, Fc, 0), alpha=0.2,
+                       res=K.Sl(b4, Fc, 0), bits=bits_4, tile_rows=4)
+    assert torch.equal(b4, b) and torch.equal(bits_4, bits_b) and torch.equal(ob4, ob)
     assert rel(ob.float(), oa.float()) < (5e-3 if out16 else 1e-6)
     # and against the fp32 reference of the two ops on the bf16-rounded data
     y4 = F.relu(F.conv2d(cat[:, :cin], bf(w3), b3, padding=1))
