@@ -850,15 +850,16 @@ __global__ __launch_bounds__(512, 4) void rdb_tail8_kernel(const nvq_conv_desc d
     bool okp[4];
     uint2 rr[4][NBL];
     float4 bb[NBL];
-    const __bf16* r16 = reinterpret_cast<const __bf16*>(dl.res) + dl.res_coff + 4 * g;
+    // (32-bit element offsets from a uniform base: the host side checks n*h*w*res_ld < 2^32)
+    const __bf16* r16 = reinterpret_cast<const __bf16*>(dl.res) + dl.res_coff;
     auto res_load = [&](int pb) {
         const int gy = ty * TH + 2 * w4 + (pb >> 1), gx = tx * TW + (pb & 1) * 16 + c;
         okp[pb] = gy < H && gx < W;
-        const size_t pix = okp[pb] ? (size_t)(n * H + gy) * W + gx : 0;
+        const unsigned off = okp[pb] ? ((unsigned)(n * H + gy) * (unsigned)W + gx) * (unsigned)dl.res_ld + 4u * g : 0u;
 #pragma unroll
-        for (int cb = 0; cb < NBL; ++cb) rr[pb][cb] = *reinterpret_cast<const uint2*>(r16 + pix * dl.res_ld + cb * 16);
+        for (int cb = 0; cb < NBL; ++cb) rr[pb][cb] = *reinterpret_cast<const uint2*>(r16 + (off + cb * 16u));
     };
-    if (!(dbg & 128)) { res_load(0); res_load(1); res_load(2); res_load(3); }
+    if (!(dbg & 128)) { res_load(0); res_load(1); }           // the first tile row now, the second behind the y4 step
     __syncthreads();                                          // every wave is done with xs / ws / wl
     __syncthreads();                                          // the y4 tile and the last lff weights (3x3 waves) are in LDS
     {
@@ -874,6 +875,7 @@ __global__ __launch_bounds__(512, 4) void rdb_tail8_kernel(const nvq_conv_desc d
             }
         }
     }
+    if (!(dbg & 128)) { res_load(2); res_load(3); }
 #pragma unroll
     for (int cb = 0; cb < NBL; ++cb) bb[cb] = ld4(dl.bias + cb * 16 + 4 * g);   // (cache hits, under the barrier)
     __syncthreads();                                      // every wave is done with t4 / wl
@@ -1241,7 +1243,9 @@ void conv_occupancy_bf16(int* out) {
 }
 
 int rdb_tail_bf16(const nvq_conv_desc& d3, const nvq_conv_desc& dl, int vec3, int vecl, hipStream_t s) {
-    NVQ_REQUIRE((size_t)d3.n * d3.h * d3.w * d3.in_ld < ((size_t)1 << 32), "rdb_tail_forward: tensor exceeds 32-bit offsets");
+    NVQ_REQUIRE((size_t)d3.n * d3.h * d3.w * d3.in_ld < ((size_t)1 << 32) &&
+                    (!dl.res || (size_t)dl.n * dl.h * dl.w * dl.res_ld < ((size_t)1 << 32)),
+                "rdb_tail_forward: tensor exceeds 32-bit offsets");
     const int tilesX = (d3.w + TW - 1) / TW, tilesY = (d3.h + TH - 1) / TH;
     const int nkc = d3.cin / KCB;
     // d3.tile_rows = 4, or an lff epilogue other than the dense block's (bias, bf16 residual over all channels, bf16 output):

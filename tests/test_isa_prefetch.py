@@ -45,6 +45,7 @@ def _main_loops(events, min_mfma):
     ("conv_bf16", "conv_bf16_kernelILi2ELi3ELb1ELi4ELi1", 72),
     ("conv_bf16", "conv_bf16_kernelILi4ELi3ELb0ELi4ELi1", 144),     # fp32-stored input
     ("conv_bf16", "rdb_tail_kernel", 80),
+    ("conv_bf16", "rdb_tail8_kernel", 72),                         # the 3x3 waves' loop of the two-role tail kernel
     ("conv_igemm", "conv_f32_kernelILi2ELi3ELi1", 288),             # exact-fp32 mode
 ])
 def test_prefetch_is_not_waited_for_before_the_mfma_section(tmp_path, source, pattern, min_mfma):
