@@ -1177,7 +1177,7 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
     const int rows = d.tile_rows == 0 && underfilled ? 8 : d.tile_rows;
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && vec_ok &&
         (rows == 162 || rows == 164 || (rows == 0 && d.cin <= 128)))
-        return conv_forward_m32(d, rows == 164 ? 4 : 2, g_debug_mode & 3, s);
+        return conv_forward_m32(d, rows == 164 ? 4 : 2, g_debug_mode & 15, s);
     if (d.ksize == 3 && NT == 32 && d.in_bf16 && d.h >= 2 * TH && rows != 8) {
         tilesY = (d.h + 2 * TH - 1) / (2 * TH);
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);

@@ -26,9 +26,13 @@ constexpr int XS32 = 40;   // bf16 per staged pixel
 // M = output channel, N = pixel: lane (x = lane & 31, h = lane >> 5) holds channels 8 j + 4 h .. + 3 (j = 0..3, registers
 // 4 j .. 4 j + 3) of pixel (row0 + r, gx).  Same arithmetic, in the same order, as conv_epilogue (conv_common.h).
 // stage != nullptr: the value goes as bf16 into the wave's [R x 32 px][STAGE_PX] LDS tile instead of global memory.
+// bias_lds: the 32 bias values as the workgroup put them into LDS at its entry (zero beyond cout), read instead of d.bias;
+// bits_pre: the pixels' ReLU-mask words (bits_mode 2) as loaded at the workgroup's entry - either spares the tile's tail a
+// memory round trip (~1.5 us for the cached bias, 2-4 us for the mask words, of ~25 us per tile: tools/tile_timeline.py).
 template <int R>
 __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16 (&acc)[R], int n, int row0, int gx, int x,
-                                                  int h, __bf16* stage) {
+                                                  int h, __bf16* stage, const float* bias_lds = nullptr,
+                                                  const unsigned* bits_pre = nullptr) {
     const int H = d.h, W = d.w;
     bool okp[R];
     size_t pixv[R];
@@ -47,11 +51,12 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
     const int bw = d.bits_words > 0 ? d.bits_words : 1;
     if (d.bits_mode == 2) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) bits_in[r] = d.bits[pixv[r] * bw];
+        for (int r = 0; r < R; ++r) bits_in[r] = bits_pre ? bits_pre[r] : d.bits[pixv[r] * bw];
     }
     if (d.bias) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bias4[j] = ld4(d.bias + (cov[j] < d.cout ? cov[j] : 0));
+        for (int j = 0; j < 4; ++j)
+            bias4[j] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + cov[j]) : ld4(d.bias + (cov[j] < d.cout ? cov[j] : 0));
     }
     if (d.res) {
 #pragma unroll
@@ -129,6 +134,21 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
 // cout <= 32 (one 32-channel slab), bf16 input (cin % 8 == 0), 16 x 32-pixel tiles; R rows per wave, NW = 16 / R waves.
 // PF: the fragments of the next (k-step, dx) group are read one group ahead of their MFMAs (needs the registers of R = 4's
 // two waves per SIMD).
+// libnvq_debug.so only (tools/tile_timeline.py): dbg & 8 = wave 0 of every workgroup leaves s_memrealtime stamps (100 MHz) and
+// its HW_ID / XCC_ID in d.bits[blockIdx.x * 16 ..] (bits_mode must be 0) - the per-CU-slot timeline of a launch.
+#ifdef NVQ_DEBUG_TOOLS
+#define NVQ_M32_STAMP(i)                                                                              \
+    do {                                                                                              \
+        if ((dbg & 8) && tid == 0) {                                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                           \
+            d.bits[blockIdx.x * 16 + 2 * (i)] = (unsigned)t_;                                         \
+            d.bits[blockIdx.x * 16 + 2 * (i) + 1] = (unsigned)(t_ >> 32);                             \
+        }                                                                                             \
+    } while (0)
+#else
+#define NVQ_M32_STAMP(i) do { } while (0)
+#endif
+
 template <int R, int NW, bool PF>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(const nvq_conv_desc d, int tilesX, int tilesY,
                                                                             int nkc, int dbg) {
@@ -147,9 +167,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
     static_assert(TH_ == 16, "16-row tiles");
     static_assert(NW * R * TW * STAGE_PX <= NPIX * XS32 + WS_HALFS, "the output staging tiles fit the LDS stages");
 
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XS32 + WS_HALFS];
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XS32 + WS_HALFS + 2 * NT];
     __bf16* xs = lds;
     __bf16* ws = lds + NPIX * XS32;
+    float* biasL = reinterpret_cast<float*>(lds + NPIX * XS32 + WS_HALFS);   // 32 floats behind the stages
     const int kcl = d.center_cin / KCB;                       // leading chunks that only have a centre tap
 
     const int tid = threadIdx.x;
@@ -157,12 +178,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = lane & 31;
     const int h = lane >> 5;
+    NVQ_M32_STAMP(0);                                         // entry
+#ifdef NVQ_DEBUG_TOOLS
+    if ((dbg & 8) && tid == 0) {
+        d.bits[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        d.bits[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
+#endif
 
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
     const int ty = bt % tilesY;
     const int n = bt / tilesY;
     const int H = d.h, W = d.w;
+    // epilogue operands fetched now: the bias into LDS (visible behind the K loop's barriers), the wave's mask words into R
+    // registers
+    if (tid < NT) biasL[tid] = d.bias && tid < d.cout ? d.bias[tid] : 0.f;
+    unsigned bits_pre[R];
+    if (d.bits_mode == 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = ty * TH_ + R * wave + r, gxx = tx * TW + x;
+            bits_pre[r] = d.bits[(gy < H && gxx < W ? (size_t)(n * H + gy) * W + gxx : 0) * (d.bits_words > 0 ? d.bits_words : 1)];
+        }
+    }
 
     f32x16 acc[R];
 #pragma unroll
@@ -278,8 +317,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
     } else {
         fetch(0, false);
     }
+    NVQ_M32_STAMP(1);                                         // first fetch issued
     for (; kc < nkc; ++kc) {
         stage_chunk(kc, false, false);
+        if (kc == 0 || kc == kcl) NVQ_M32_STAMP(2);           // first full chunk staged (its loads have arrived)
         if (dbg & 1) continue;
         // six groups (k-step, dx); a group reads the R + 2 halo-row fragments of its column shift and its three weight
         // fragments (dy = 0..2) and issues 3 R MFMAs
@@ -340,13 +381,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
         }
     }
 
+    NVQ_M32_STAMP(3);                                         // K loop done
     const int row0 = ty * TH_ + R * wave, gx = tx * TW + x;
     const bool can_stage = d.out_bf16 && d.cout_store >= NT;  // workgroup-uniform
     if (can_stage) {
         // full 32-channel bf16 output: stage the wave's rows in LDS and store whole 64-byte pixel rows
         __syncthreads();                                      // every wave is done reading xs / ws
         __bf16* stage = lds + wave * (R * TW * STAGE_PX);
-        conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, stage);
+        conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, stage, biasL, bits_pre);
+        NVQ_M32_STAMP(4);                                     // epilogue arithmetic done (operands arrived)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
@@ -359,9 +402,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
                 *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gxx) * d.out_ld + d.out_coff + 8 * piece) =
                     *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX + 8 * piece);
         }
+        NVQ_M32_STAMP(5);                                     // stores issued
         return;
     }
-    conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, nullptr);
+    conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, nullptr, biasL, bits_pre);
 }
 
 // variant: 2 = two rows per wave, 8 waves; 4 = four rows per wave, 4 waves (fragments read one group ahead)

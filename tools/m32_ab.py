@@ -50,7 +50,10 @@ for mode, cins in (("fwd", (64, 96, 128, 160)), ("bwd", (64, 96, 128, 160, 192))
                 else:
                     K.conv_forward(cat.inp(cin), wp, None, K.Sl(out), 3, math=K.MATH_BF16, bits=bits_r, bits_mode=2,
                                    center_cin=ctr, tile_rows=v)
-            res[v] = timeit(run)
+            try:
+                res[v] = timeit(run)
+            except RuntimeError:                       # a forced form that does not take this launch
+                res[v] = float('nan')
             outs[v] = (out.float(), bw.clone())
         ref = outs[0]
         nbytes = N * H * W * ((cin + 32) * 2 + 4)

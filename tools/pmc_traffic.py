@@ -27,7 +27,7 @@ def label_of(kernel_name: str):
     m = re.search(r"(wgrad_bf16_kernel|wgrad_f32_kernel)<(\d+)", kernel_name)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    return "rdb_tail_kernel" if "rdb_tail_kernel" in kernel_name else None
+    return "rdb_tail_kernel" if ("rdb_tail_kernel" in kernel_name or "rdb_tail8_kernel" in kernel_name) else None
 
 
 def per_kernel(path, counter):
