@@ -358,6 +358,36 @@ def test_warp_forward_backward(K, C, N, H, W, mag, gather):
             K.warp_backward(K.Sl(dal, C, 2 * C), K.Sl(fb), flb, K.Sl(dfeat), dflow, gather=False, overwrite=True)
 
 
+@pytest.mark.parametrize("dfeat_bf16", [False, True])
+def test_warp_backward_with_a_fifth_of_the_sources_far_away(K, dfeat_bf16):
+    """Overwrite-mode warp backward on a motion field where 20 % of the pixels move 5 - 8 px (beyond the gather pass's 9 x 9
+    window): those sources go through warp_bwd_far_kernel (a wave per far source: corner x 16-byte channel piece per lane),
+    here thousands of them in every direction, several per wave, onto destinations that also receive near sources; fp32 and
+    bf16 gradient tensors, against autograd through the oracle's grid_sample."""
+    C, N, H, W = 64, 2, 40, 72
+    g = torch.Generator().manual_seed(5)
+    feat = rnd(N, C, H, W).requires_grad_()
+    far = torch.rand(N, 1, H, W, generator=g) < 0.2
+    ang = torch.rand(N, 1, H, W, generator=g) * 6.2831853
+    r = 5.0 + 3.0 * torch.rand(N, 1, H, W, generator=g)
+    fl = 0.5 * rnd(N, 2, H, W, seed=2) + torch.where(far, r, torch.zeros(())) * torch.cat([torch.cos(ang), torch.sin(ang)], 1)
+    flow = fl.requires_grad_()
+    dy = rnd(N, C, H, W, seed=4)
+    sr_oracle.warp(feat, flow).backward(dy)
+    assert 0.15 < far.float().mean().item() < 0.25
+    fb, flb, dal = to_nhwc(feat.detach()), to_nhwc(flow.detach(), 4), to_nhwc(dy)
+    dfeat = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=torch.bfloat16 if dfeat_bf16 else torch.float32)
+    dflow = torch.empty(N, H, W, 4, device="cuda")
+    K.warp_backward(K.Sl(dal), K.Sl(fb), flb, K.Sl(dfeat), dflow, overwrite=True)
+    # bf16: a destination's addends are rounded one by one (compare-and-swap per word), a few of them per pixel here
+    assert rel(from_nhwc(dfeat.float()), feat.grad) < (2e-2 if dfeat_bf16 else 5e-5)
+    assert rel(from_nhwc(dflow, 2), flow.grad) < 2e-4
+    # the accumulate mode (all sources through the src pass) gives the same sums
+    dfeat2 = torch.zeros(N, H, W, C, device="cuda")
+    K.warp_backward(K.Sl(dal), K.Sl(fb), flb, K.Sl(dfeat2), dflow)
+    assert rel(from_nhwc(dfeat2), feat.grad) < 5e-5
+
+
 @pytest.mark.parametrize("overwrite", [False, True])
 def test_warp_backward_contracting_flow_overflows_the_hit_list(K, overwrite):
     """A flow that sends a 7 x 7 neighbourhood to (nearly) one point gives destination pixels more contributing sources than the
