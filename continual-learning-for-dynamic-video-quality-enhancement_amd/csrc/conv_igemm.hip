@@ -376,13 +376,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const nvq_wgrad_desc 
 constexpr int WR_Q = 8, WR_E = 256 / WR_Q;
 // Blocks past `wblocks` do the bias gradient of the same launch (bp != NULL; one wave per output channel: bias_part[split][coc][32]
 // summed over the splits in double) - a launch of its own cost as much as its arithmetic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
-                                                           int taps, int cout, int cin_w, float alpha, int accumulate,
-                                                           float* __restrict__ dw, int wblocks, const float* __restrict__ bp,
-                                                           float* __restrict__ dbias) {
-    __shared__ double sh[WR_Q][WR_E];
-    if ((int)blockIdx.x >= wblocks) {                         // (block-uniform)
-        const int co = ((int)blockIdx.x - wblocks) * 4 + (threadIdx.x >> 6);
+// bx: the block's index within its job (the launch's blockIdx.x)
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int nsplit, int nci, int nco, int taps,
+                                                  int cout, int cin_w, float alpha, int accumulate, float* __restrict__ dw,
+                                                  int wblocks, const float* __restrict__ bp, float* __restrict__ dbias,
+                                                  int bx, double (&sh)[WR_Q][WR_E]) {
+    if (bx >= wblocks) {                                      // (block-uniform)
+        const int co = (bx - wblocks) * 4 + (threadIdx.x >> 6);
         const int lane = threadIdx.x & 63;
         if (co >= cout) return;
         const int coc = co / WG_C, col = co % WG_C;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     const long total = (long)nci * nco * taps * WG_C * WG_C;
     const int e = threadIdx.x & (WR_E - 1), q = threadIdx.x / WR_E;
-    for (long base = (long)blockIdx.x * WR_E; base < total; base += (long)wblocks * WR_E) {     // (uniform trip count per block)
+    for (long base = (long)bx * WR_E; base < total; base += (long)wblocks * WR_E) {           // (uniform trip count per block)
         const long idx = base + e;
         // 4 independent chains: the split loop is a chain of dependent HBM/L2 loads otherwise
         double s4[4] = {0, 0, 0, 0};
@@ -430,6 +430,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int nci, int nco,
+                                                           int taps, int cout, int cin_w, float alpha, int accumulate,
+                                                           float* __restrict__ dw, int wblocks, const float* __restrict__ bp,
+                                                           float* __restrict__ dbias) {
+    __shared__ double sh[WR_Q][WR_E];
+    wgrad_reduce_body(part, nsplit, nci, nco, taps, cout, cin_w, alpha, accumulate, dw, wblocks, bp, dbias, (int)blockIdx.x, sh);
+}
+
+// Several layers' reduces in one launch (nvq_wgrad_reduce_batch): grid = (blocks, jobs); job y takes the first
+// min(its own block count, gridDim.x) blocks of row y.  On launch-bound steps (the 64x64 continual-learning step: 61 reduces of
+// 6 us, each a dependent launch between two weight-gradient kernels) a dense block's six reduces cost one launch.
+constexpr int WR_MAX_JOBS = 16;
+struct WgradReduceTable { nvq_wgrad_reduce_job j[WR_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceTable t) {
+    __shared__ double sh[WR_Q][WR_E];
+    const nvq_wgrad_reduce_job& j = t.j[blockIdx.y];
+    const long total = (long)j.nci * j.nco * j.taps * WG_C * WG_C;
+    const int bblk = j.dbias ? (j.cout + 3) / 4 : 0;
+    long nblk = (total + WR_E - 1) / WR_E;
+    if (nblk > (long)gridDim.x - bblk) nblk = (long)gridDim.x - bblk;
+    if ((int)blockIdx.x >= nblk + bblk) return;               // (block-uniform)
+    wgrad_reduce_body(j.part, j.nsplit, j.nci, j.nco, j.taps, j.cout, j.cin_w, j.alpha, j.accumulate, j.dw, (int)nblk,
+                      j.bias_part, j.dbias, (int)blockIdx.x, sh);
 }
 
 // (for kernels of other translation units that write partial slabs in this layout: pw_bwd.hip)
@@ -605,6 +630,7 @@ int nvq_debug_conv_occupancy(int* out6) { conv_occupancy_bf16(out6); return NVQ_
 
 size_t nvq_sizeof_conv_desc(void) { return sizeof(nvq_conv_desc); }
 size_t nvq_sizeof_wgrad_desc(void) { return sizeof(nvq_wgrad_desc); }
+size_t nvq_sizeof_wgrad_reduce_job(void) { return sizeof(nvq_wgrad_reduce_job); }
 
 static int epilogue_vec_ok(const nvq_conv_desc& d) {
     int v = d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && d.cout_store % 4 == 0 && aligned16(d.out) && (d.cout % 4 == 0 || !d.bias);
@@ -743,7 +769,8 @@ size_t nvq_wgrad_workspace_bytes(void) {
     return (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C * sizeof(float) + (size_t)512 * 256 * sizeof(float);
 }
 
-int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
+// the weight-gradient kernel of *dp (partial slabs into its workspace); *job = the reduce that finishes it
+static int wgrad_partial(const nvq_wgrad_desc* dp, nvq_wgrad_reduce_job* job, void* stream) {
     const nvq_wgrad_desc d = *dp;
     NVQ_REQUIRE(d.math == NVQ_MATH_F32 || d.math == NVQ_MATH_BF16, "conv_wgrad: math mode %d", d.math);
     NVQ_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv_wgrad: ksize %d", d.ksize);
@@ -790,9 +817,49 @@ int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
     }
     if (rc) return rc;
     // bias_part[split][coc][32] written by the ci-chunk-0 workgroups (channel = coc*32 + lane), reduced by the same launch
-    return launch_wgrad_reduce_bias(d.workspace, nsplit, nci, nco, taps, d.cout, d.cin_w, d.alpha, d.accumulate, d.dw,
-                                    d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C, d.dbias, s);
+    *job = nvq_wgrad_reduce_job{d.workspace, d.workspace + (size_t)WGRAD_MAX_SLABS * 9 * WG_C * WG_C, d.dw, d.dbias, nsplit, nci,
+                                nco, taps, d.cout, d.cin_w, d.alpha, d.accumulate};
+    return NVQ_OK;
 }
+
+int nvq_conv_wgrad(const nvq_wgrad_desc* dp, void* stream) {
+    nvq_wgrad_reduce_job j;
+    const int rc = wgrad_partial(dp, &j, stream);
+    if (rc) return rc;
+    return launch_wgrad_reduce_bias(j.part, j.nsplit, j.nci, j.nco, j.taps, j.cout, j.cin_w, j.alpha, j.accumulate, j.dw,
+                                    j.bias_part, j.dbias, (hipStream_t)stream);
+}
+
+int nvq_conv_wgrad_partial(const nvq_wgrad_desc* dp, nvq_wgrad_reduce_job* job, void* stream) {
+    NVQ_REQUIRE(job != nullptr, "conv_wgrad_partial: job");
+    return wgrad_partial(dp, job, stream);
+}
+
+int nvq_wgrad_reduce_batch(const nvq_wgrad_reduce_job* jobs, int n, void* stream) {
+    NVQ_REQUIRE(n >= 0 && (n == 0 || jobs != nullptr), "wgrad_reduce_batch: jobs");
+    for (int i = 0; i < n; ++i)
+        NVQ_REQUIRE(jobs[i].part && jobs[i].dw && jobs[i].nsplit > 0 && jobs[i].nci > 0 && jobs[i].nco > 0 &&
+                        (jobs[i].taps == 1 || jobs[i].taps == 9) && (!jobs[i].dbias || jobs[i].bias_part),
+                    "wgrad_reduce_batch: job %d is not one nvq_conv_wgrad_partial filled in", i);
+    for (int i0 = 0; i0 < n; i0 += WR_MAX_JOBS) {
+        const int m = n - i0 < WR_MAX_JOBS ? n - i0 : WR_MAX_JOBS;
+        WgradReduceTable t;
+        long need = 1;
+        for (int i = 0; i < m; ++i) {
+            t.j[i] = jobs[i0 + i];
+            const long total = (long)t.j[i].nci * t.j[i].nco * t.j[i].taps * WG_C * WG_C;
+            long b = ceil_div(total, WR_E);
+            if (b > 1024) b = 1024;
+            b += t.j[i].dbias ? ceil_div(t.j[i].cout, 4) : 0;
+            if (b > need) need = b;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)need, (unsigned)m), dim3(256), 0, (hipStream_t)stream, t);
+        const int rc = check_launch("wgrad_reduce_batch");
+        if (rc) return rc;
+    }
+    return NVQ_OK;
+}
+
 
 int nvq_colsum(const float* x, int x_ld, int x_coff, int C, long npix, float alpha, float* out,
                float* workspace, size_t workspace_bytes, int accumulate, void* stream) {

@@ -77,6 +77,20 @@ def workspace(device) -> torch.Tensor:
     return ws
 
 
+_ws_multi_cache: Dict = {}
+SMALL_STEP_PIXELS = int(os.environ.get("NVQ_SMALL_STEP_PIXELS", str(16 * 128 * 128)))   # batch x H x W up to which a step is launch-bound
+
+
+def workspace_slots(device, n: int) -> "list[torch.Tensor]":
+    """n weight-gradient workspaces that can be in use at the same time (deferred reduces of a dense block: small steps only)"""
+    ws = _ws_multi_cache.get((device, n))
+    if ws is None:
+        k = K.wgrad_workspace_bytes() // 4 + 1024
+        flat = torch.empty(n * k, dtype=torch.float32, device=device)
+        ws = _ws_multi_cache[(device, n)] = [flat[i * k:(i + 1) * k] for i in range(n)]
+    return ws
+
+
 class Geometry:
     def __init__(self, frames: torch.Tensor, F: int, nblocks: int, scale: int):
         self.B, self.T, self.Cimg, self.H, self.W = frames.shape
@@ -338,8 +352,8 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
 
 def _wgrad(x: Sl, cin_w: int, dy: Sl, G: Dict[str, torch.Tensor], wname: str, bname: Optional[str], ws, ksize,
-           alpha=1.0, math=K.MATH_F32):
-    K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math)
+           alpha=1.0, math=K.MATH_F32, defer=None):
+    K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math, defer=defer)
 
 
 def extract_features(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, math: int = K.MATH_F32,
@@ -417,12 +431,20 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
         reqs += [(wb[j], False, F + GROWTH * j, None) for j in range(LAYERS)] + [(wbx, False, g.CAT, None)]
     mirror = K.conv_pack_many(reqs, math)
+    # Launch-bound steps (small frames: the 64x64 continual-learning step is ~330 dependent launches of a few microseconds): a
+    # block's six weight gradients leave their partial sums in six workspaces and ONE launch reduces them (nvq_wgrad_reduce_batch;
+    # same sums, same order) - 40 launches less per step.  Large frames keep the reduce behind each kernel, where its partial
+    # slabs (up to 56 MB) are still in the last-level cache.
+    small = g.B * g.H * g.W <= SMALL_STEP_PIXELS and K.TIMER is None
+    wsl = workspace_slots(dev, LAYERS + 1) if small else [ws] * (LAYERS + 1)
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
         gout = dcat.x()
-        _wgrad(cat.inp(g.CAT), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", ws, 1, alpha=0.2, math=math)
+        jobs = [] if small else None
+        _wgrad(cat.inp(g.CAT), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", wsl[LAYERS], 1, alpha=0.2, math=math,
+               defer=jobs)
         wpb = mirror[k * (LAYERS + 1):(k + 1) * (LAYERS + 1)]     # packs of Wb_4 .. Wb_0, Wb_x
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
@@ -434,8 +456,10 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                 K.conv_forward(dcat.inp(cinb), wpb[LAYERS - 1 - i], None, dy, 3,
                                mask=cat.y(i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
             cin = F + GROWTH * i
-            _wgrad(cat.inp(cin), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", ws, 3,
-                   math=math)
+            _wgrad(cat.inp(cin), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", wsl[i], 3,
+                   math=math, defer=jobs)
+        if small:
+            K.wgrad_reduce_batch(jobs)
         nxt = dcats[(k - 1) & 1].x() if k > 0 else Sl(dagg)
         K.conv_forward(dcat.inp(g.CAT), wpb[LAYERS], None, nxt, 3, res=gout, math=math, center_cin=ctr)
     K.TIMER_TAG = ""

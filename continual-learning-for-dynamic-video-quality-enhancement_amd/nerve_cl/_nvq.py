@@ -70,6 +70,14 @@ class WgradDesc(C.Structure):
     ]
 
 
+class WgradReduceJob(C.Structure):
+    _fields_ = [
+        ("part", vp), ("bias_part", vp), ("dw", vp), ("dbias", vp),
+        ("nsplit", ci), ("nci", ci), ("nco", ci), ("taps", ci), ("cout", ci), ("cin_w", ci),
+        ("alpha", cf), ("accumulate", ci),
+    ]
+
+
 _IP = C.POINTER(ci)
 
 # name -> (restype, argtypes); must list every symbol declared in include/nvq.h
@@ -85,7 +93,10 @@ SIGNATURES = {
     "nvq_sizeof_conv_desc": (sz, []),
     "nvq_wgrad_workspace_bytes": (sz, []),
     "nvq_conv_wgrad": (ci, [C.POINTER(WgradDesc), vp]),
+    "nvq_conv_wgrad_partial": (ci, [C.POINTER(WgradDesc), C.POINTER(WgradReduceJob), vp]),
+    "nvq_wgrad_reduce_batch": (ci, [C.POINTER(WgradReduceJob), ci, vp]),
     "nvq_sizeof_wgrad_desc": (sz, []),
+    "nvq_sizeof_wgrad_reduce_job": (sz, []),
     "nvq_conv_pack_batch": (ci, [vp, ci, ci, vp]),
     "nvq_head_forward": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, vp, ci, vp, ci, ci, vp, ci, vp]),
     "nvq_head_wgrad": (ci, [vp, ci, ci, ci, ci, ci, _IP, ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp, sz, ci, ci, vp]),
@@ -173,6 +184,7 @@ def lib():
             fn.argtypes = args
         assert l.nvq_sizeof_conv_desc() == C.sizeof(ConvDesc), "nvq_conv_desc layout mismatch"
         assert l.nvq_sizeof_wgrad_desc() == C.sizeof(WgradDesc), "nvq_wgrad_desc layout mismatch"
+        assert l.nvq_sizeof_wgrad_reduce_job() == C.sizeof(WgradReduceJob), "nvq_wgrad_reduce_job layout mismatch"
         _lib = l
     return _lib
 
@@ -516,9 +528,11 @@ def rdb_backward_weights(lff: torch.Tensor, ws: Sequence[torch.Tensor], F: int):
 
 def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torch.Tensor],
                ws: torch.Tensor, ksize: int, *, alpha: float = 1.0, accumulate: bool = False,
-               math: int = MATH_F32, variant: int = 0) -> None:
+               math: int = MATH_F32, variant: int = 0, defer: Optional[list] = None) -> None:
+    """defer: a list -> only the weight-gradient kernel runs (nvq_conv_wgrad_partial); its reduce job is appended to the list
+    and finished by wgrad_reduce_batch(list).  `ws` must then be this call's own until that batch has run."""
     n, h, w, _ = x.t.shape
-    ev0 = TIMER.start() if TIMER is not None else None
+    ev0 = TIMER.start() if TIMER is not None and defer is None else None
     d = WgradDesc()
     d.x, d.x_ld, d.x_coff, d.cin, d.cin_w = ptr(x.t), x.ld, x.coff, x.c, cin_w
     d.dy, d.dy_ld, d.dy_coff, d.cout = ptr(dy.t), dy.ld, dy.coff, dy.c
@@ -528,11 +542,25 @@ def conv_wgrad(x: Sl, cin_w: int, dy: Sl, dw: torch.Tensor, dbias: Optional[torc
     d.alpha, d.accumulate, d.math = alpha, int(accumulate), math
     d.x_bf16, d.dy_bf16, d.x_plane = x.bf16, dy.bf16, x.plane
     d.variant = variant
+    if defer is not None:
+        job = WgradReduceJob()
+        check(lib().nvq_conv_wgrad_partial(C.byref(d), C.byref(job), stream()), "nvq_conv_wgrad_partial")
+        defer.append((job, (ws, dw, dbias)))               # (the tensors stay alive with the job)
+        return
     check(lib().nvq_conv_wgrad(C.byref(d), stream()), "nvq_conv_wgrad")
     if ev0 is not None:
         TIMER.stop(ev0, f"wgrad_{'bf16' if math == MATH_BF16 else 'f32'}_kernel<{ksize}>", 2.0 * n * h * w * cin_w * dy.c * ksize * ksize,
                    n * h * w * (cin_w * (2.0 if x.bf16 else 4.0) + dy.c * (2.0 if dy.bf16 else 4.0)),
                    f"n{n} cin{cin_w}{'h' if x.bf16 else ''} cout{dy.c}{'h' if dy.bf16 else ''}")
+
+
+def wgrad_reduce_batch(jobs: list) -> None:
+    """Finish the weight gradients deferred into `jobs` (conv_wgrad(..., defer=jobs)): up to 16 reduces per launch."""
+    if not jobs:
+        return
+    arr = (WgradReduceJob * len(jobs))(*[j for j, _ in jobs])
+    check(lib().nvq_wgrad_reduce_batch(arr, len(jobs), stream()), "nvq_wgrad_reduce_batch")
+    jobs.clear()
 
 
 # ----------------------------------------------------------------------------- feature extractor

@@ -237,7 +237,8 @@ class FrameRecoveryNet(BucketedNet):
                 corruption_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, C, H, W = corrupted_frame.shape
         _nvq.require_device(corrupted_frame, "corrupted_frame")
-        _nvq.require_device(next(self.parameters()), "FrameRecoveryNet parameters")
+        named = self._named_params()
+        _nvq.require_device(named[0][1], "FrameRecoveryNet parameters")
         if C != 3:
             raise RuntimeError(f"expected 3 image channels, got {C}")
         if reference_frames.dim() != 5 or reference_frames.shape[0] != B or tuple(reference_frames.shape[2:]) != (C, H, W):
@@ -250,7 +251,7 @@ class FrameRecoveryNet(BucketedNet):
             mask = torch.zeros(B, 1, H, W, dtype=torch.float32, device=frame.device)
         else:
             mask = corruption_mask.detach().to(frame.device, torch.float32).contiguous()
-        params = [p for _, p in self.named_parameters()]
+        params = [p for _, p in named]
         with torch.cuda.device(frame.device):
             return _FRFunction.apply(self, frame, refs, mask, *params)
 

@@ -256,7 +256,8 @@ class SuperResolutionNet(BucketedNet):
         """(B,T,C,H,W) low-resolution clip -> (B,C,H*s,W*s) super-resolved centre frame."""
         B, T, C, H, W = lr_frames.shape
         _nvq.require_device(lr_frames, "lr_frames")
-        _nvq.require_device(next(self.parameters()), "SuperResolutionNet parameters")
+        named = self._named_params()
+        _nvq.require_device(named[0][1], "SuperResolutionNet parameters")
         if T != self.num_frames:
             raise RuntimeError(f"expected {self.num_frames} frames (temporal_window={self.temporal_window}), got {T}")
         if C != self._Cimg:
@@ -264,7 +265,7 @@ class SuperResolutionNet(BucketedNet):
         if H < 2 or W < 2:
             raise RuntimeError("frames must be at least 2x2 (grid_sample normalisation divides by size-1)")
         frames = lr_frames.detach().to(torch.float32).contiguous()
-        params = [p for _, p in self.named_parameters()]
+        params = [p for _, p in named]
         with torch.cuda.device(frames.device):      # the kernels launch on the CURRENT device's stream
             out = _SRFunction.apply(self, frames, bool(return_intermediate), *params)
         if return_intermediate:
@@ -367,9 +368,10 @@ class LightweightSuperResolution(BucketedNet):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> (B,3,H*s,W*s)."""
         _nvq.require_device(x, "x")
-        _nvq.require_device(next(self.parameters()), "LightweightSuperResolution parameters")
+        named = self._named_params()
+        _nvq.require_device(named[0][1], "LightweightSuperResolution parameters")
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected (B,3,H,W), got {tuple(x.shape)}")
-        params = [p for _, p in self.named_parameters()]
+        params = [p for _, p in named]
         with torch.cuda.device(x.device):
             return _LightFunction.apply(self, x.detach().to(torch.float32).contiguous(), *params)

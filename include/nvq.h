@@ -165,7 +165,18 @@ typedef struct nvq_wgrad_desc {
 } nvq_wgrad_desc;
 size_t nvq_wgrad_workspace_bytes(void);   /* upper bound valid for every shape */
 int nvq_conv_wgrad(const nvq_wgrad_desc* d, void* stream);
+/* The same in two halves, for steps that are bound by their launch count (the 64x64 continual-learning step): the weight-gradient
+ * kernel alone leaves its partial sums in d->workspace and describes the reduce that finishes it in *job; nvq_wgrad_reduce_batch
+ * runs up to 16 such reduces per launch (any n).  Every job needs a workspace of its own until its batch has run.  Results equal
+ * nvq_conv_wgrad's bit for bit (same sums, same order). */
+typedef struct {
+    const float* part; const float* bias_part; float* dw; float* dbias;
+    int nsplit, nci, nco, taps, cout, cin_w; float alpha; int accumulate;
+} nvq_wgrad_reduce_job;
+int nvq_conv_wgrad_partial(const nvq_wgrad_desc* d, nvq_wgrad_reduce_job* job, void* stream);
+int nvq_wgrad_reduce_batch(const nvq_wgrad_reduce_job* jobs, int n, void* stream);
 size_t nvq_sizeof_wgrad_desc(void);
+size_t nvq_sizeof_wgrad_reduce_job(void);
 
 /* Backward of  pointwise 1x1 conv (no bias) -> BatchNorm2d -> ReLU  of a DepthwiseSeparableConv (efficient_layers.py:49-66) in
  * the bf16 mode, 64 channels in and out: what nvq_bn_relu_backward + nvq_conv_forward (transposed pack) + nvq_conv_wgrad do

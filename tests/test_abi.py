@@ -32,6 +32,8 @@ def _ctype_of(decl: str):
         return C.POINTER(_nvq.ConvDesc)
     if "nvq_wgrad_desc" in decl:
         return C.POINTER(_nvq.WgradDesc)
+    if "nvq_wgrad_reduce_job" in decl:
+        return C.POINTER(_nvq.WgradReduceJob)
     if "*" in decl:
         if re.match(r"const int\s*\*\s*\w*_host$", decl):
             return C.POINTER(C.c_int)

@@ -718,6 +718,36 @@ def test_conv_bf16_stored_weight_gradient(K, xb, yb, cin, cout, k, N, H, W):
     assert rel(db, dy.sum((0, 2, 3))) < TOL
 
 
+def test_conv_wgrad_in_two_halves_with_batched_reduces(K):
+    """nvq_conv_wgrad_partial + nvq_wgrad_reduce_batch: 19 weight gradients of different shapes (1x1 / 3x3, bf16 and fp32 tensors,
+    with and without bias, alpha / accumulate) left as partial sums in workspaces of their own and finished by two batched
+    launches (16 + 3 jobs): bit-identical to nvq_conv_wgrad on the same operands."""
+    shapes = [(64, 32, 3), (96, 32, 3), (224, 64, 1), (64, 64, 3), (128, 32, 3), (160, 32, 3), (96, 72, 1), (192, 32, 3),
+              (96, 128, 3)]
+    N, H, W = 2, 14, 40
+    jobs, ref, got = [], [], []
+    for i in range(19):
+        cin, cout, k = shapes[i % len(shapes)]
+        bf = i % 3 != 2
+        x = rnd(N, cin, H, W, seed=i)
+        dy = rnd(N, cout, H, W, seed=100 + i)
+        xs = to_nhwc_bf16(x) if bf else to_nhwc(x)
+        ds = to_nhwc_bf16(dy, cout + 8, 8) if bf else to_nhwc(dy, cout + 8, 8)
+        acc, alpha, bias = i % 4 == 1, (0.2 if i % 5 == 0 else 1.0), i % 6 != 3
+        mk = lambda: (torch.full((cout, cin, k, k), 0.5, device="cuda"), torch.full((cout,), -0.25, device="cuda") if bias else None)
+        dw0, db0 = mk()
+        K.conv_wgrad(K.Sl(xs), cin, K.Sl(ds, cout, 8), dw0, db0, ws_tensor(K), k, alpha=alpha, accumulate=acc, math=K.MATH_BF16)
+        dw1, db1 = mk()
+        K.conv_wgrad(K.Sl(xs), cin, K.Sl(ds, cout, 8), dw1, db1, torch.empty_like(ws_tensor(K)), k, alpha=alpha, accumulate=acc,
+                     math=K.MATH_BF16, defer=jobs)
+        ref.append((dw0, db0)); got.append((dw1, db1))
+    assert len(jobs) == 19 and all(torch.equal(g[0], torch.full_like(g[0], 0.5)) for g in got)   # nothing reduced yet
+    K.wgrad_reduce_batch(jobs)
+    assert jobs == []
+    for (dw0, db0), (dw1, db1) in zip(ref, got):
+        assert torch.equal(dw0, dw1) and (db0 is None or torch.equal(db0, db1))
+
+
 @pytest.mark.parametrize("Fc,cin,N,H,W", [(64, 96, 2, 16, 64), (64, 96, 1, 21, 45), (64, 128, 2, 9, 33), (64, 160, 3, 17, 70),
                                             (64, 192, 1, 40, 96), (32, 96, 2, 8, 32), (32, 160, 1, 13, 50), (128, 192, 1, 12, 40),
                                             (64, 192, 5, 37, 130)])
