@@ -91,6 +91,24 @@ def workspace_slots(device, n: int) -> "list[torch.Tensor]":
     return ws
 
 
+class _ReduceQueue:
+    """Deferred weight-gradient reduces of a launch-bound step: every _wgrad takes the next free workspace slot and leaves its
+    reduce in the queue; a full queue (and the end of the pass) is one nvq_wgrad_reduce_batch launch."""
+    SLOTS = 8
+
+    def __init__(self, device):
+        self.slots = workspace_slots(device, self.SLOTS)
+        self.jobs: list = []
+
+    def ws(self) -> torch.Tensor:
+        if len(self.jobs) == self.SLOTS:
+            self.flush()
+        return self.slots[len(self.jobs)]
+
+    def flush(self) -> None:
+        K.wgrad_reduce_batch(self.jobs)
+
+
 class Geometry:
     def __init__(self, frames: torch.Tensor, F: int, nblocks: int, scale: int):
         self.B, self.T, self.Cimg, self.H, self.W = frames.shape
@@ -352,8 +370,12 @@ def forward(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, nblocks: i
 
 
 def _wgrad(x: Sl, cin_w: int, dy: Sl, G: Dict[str, torch.Tensor], wname: str, bname: Optional[str], ws, ksize,
-           alpha=1.0, math=K.MATH_F32, defer=None):
-    K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math, defer=defer)
+           alpha=1.0, math=K.MATH_F32):
+    """ws: the shared workspace (reduce behind the kernel) or a _ReduceQueue (reduce deferred into its next batch)"""
+    if isinstance(ws, _ReduceQueue):
+        K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws.ws(), ksize, alpha=alpha, math=math, defer=ws.jobs)
+    else:
+        K.conv_wgrad(x, cin_w, dy, G[wname], G[bname] if bname else None, ws, ksize, alpha=alpha, math=math)
 
 
 def extract_features(P: Dict[str, torch.Tensor], frames: torch.Tensor, F: int, math: int = K.MATH_F32,
@@ -379,6 +401,12 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     B, T, H, W, NI, NO, c, F = g.B, g.T, g.H, g.W, g.NI, g.NO, g.c, g.F
     math, act_dtype = sv.math, sv.act_dtype
     ws = workspace(dev)
+    # Launch-bound steps (small frames: the 64x64 continual-learning step is ~330 dependent launches of a few microseconds): the
+    # conv weight gradients leave their partial sums in workspaces of their own and one launch per eight of them does the reduces
+    # (nvq_wgrad_reduce_batch; same sums, same order) - ~50 launches less per step.  Large frames keep the reduce behind each
+    # kernel, where its partial slabs (up to 56 MB) are still in the last-level cache.
+    small = g.B * g.H * g.W <= SMALL_STEP_PIXELS and K.TIMER is None
+    wq = _ReduceQueue(dev) if small else ws
     nb = g.NB
     # the transposed packs of the input-gradient convs outside the dense blocks in one launch (the blocks' mirror-form packs
     # have a batched launch of their own below)
@@ -394,7 +422,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     # ---- upsampler tail
     du = _new(dev, B, H, W, g.Up)
     K.shuffle_clamp_backward(dout, sv.passmask, g.s, du)
-    _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", ws, 3, math=math)
+    _wgrad(Sl(sv.fused), F, Sl(du, g.U), G, "upsampler.conv.weight", "upsampler.conv.bias", wq, 3, math=math)
     # bf16 activation mode with reference frames: the feature gradient is FINISHED by the two correlation gradients, which write it
     # as bf16 (dfeat16, below).  Its terms then never meet in an fp32 accumulator: the upsampler input-gradient conv's second
     # output, the attention path's slice of daligned and the warp gradient are bf16 addends of those last passes (no fp32
@@ -411,7 +439,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                    out2=Sl(dfeat_c16) if feat16 else Sl(dfeat_c), mask=Sl(sv.gr), mask_c0=0, mask_c1=F, math=math)
     # ---- gff
     xN = sv.xloc(nb)
-    _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", ws, 3, math=math)
+    _wgrad(xN, F, Sl(dg), G, "gff.0.weight", "gff.0.bias", wq, 3, math=math)
     # gradient buffers of the dense blocks, layout [gout(F) | dy_4 | dy_3 | dy_2 | dy_1 | dy_0] (ping-pong)
     dcats = [K.CatBuf(dev, B, H, W, F, LAYERS, g.CATLD, act_dtype, sv.planar) for _ in range(2)] if nb else []
     dagg = _new(dev, B, H, W, F, dtype=sv.cbam_dtype)
@@ -431,20 +459,12 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         wb, wbx = K.rdb_backward_weights(P[pre + "lff.weight"], [P[pre + f"layers.{i}.0.weight"] for i in range(LAYERS)], F)
         reqs += [(wb[j], False, F + GROWTH * j, None) for j in range(LAYERS)] + [(wbx, False, g.CAT, None)]
     mirror = K.conv_pack_many(reqs, math)
-    # Launch-bound steps (small frames: the 64x64 continual-learning step is ~330 dependent launches of a few microseconds): a
-    # block's six weight gradients leave their partial sums in six workspaces and ONE launch reduces them (nvq_wgrad_reduce_batch;
-    # same sums, same order) - 40 launches less per step.  Large frames keep the reduce behind each kernel, where its partial
-    # slabs (up to 56 MB) are still in the last-level cache.
-    small = g.B * g.H * g.W <= SMALL_STEP_PIXELS and K.TIMER is None
-    wsl = workspace_slots(dev, LAYERS + 1) if small else [ws] * (LAYERS + 1)
     for k in range(nb - 1, -1, -1):
         cat = sv.cats[k]
         dcat = dcats[k & 1]
         pre = f"residual_blocks.{k}."
         gout = dcat.x()
-        jobs = [] if small else None
-        _wgrad(cat.inp(g.CAT), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", wsl[LAYERS], 1, alpha=0.2, math=math,
-               defer=jobs)
+        _wgrad(cat.inp(g.CAT), g.CAT, gout, G, pre + "lff.weight", pre + "lff.bias", wq, 1, alpha=0.2, math=math)
         wpb = mirror[k * (LAYERS + 1):(k + 1) * (LAYERS + 1)]     # packs of Wb_4 .. Wb_0, Wb_x
         for i in range(LAYERS - 1, -1, -1):
             cinb = F + GROWTH * (LAYERS - 1 - i)            # channels [0, cinb) = gout, dy_4 .. dy_{i+1}
@@ -456,10 +476,8 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
                 K.conv_forward(dcat.inp(cinb), wpb[LAYERS - 1 - i], None, dy, 3,
                                mask=cat.y(i), mask_c0=0, mask_c1=GROWTH, math=math, center_cin=ctr)
             cin = F + GROWTH * i
-            _wgrad(cat.inp(cin), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", wsl[i], 3,
-                   math=math, defer=jobs)
-        if small:
-            K.wgrad_reduce_batch(jobs)
+            _wgrad(cat.inp(cin), cin, dy, G, pre + f"layers.{i}.0.weight", pre + f"layers.{i}.0.bias", wq, 3,
+                   math=math)
         nxt = dcats[(k - 1) & 1].x() if k > 0 else Sl(dagg)
         K.conv_forward(dcat.inp(g.CAT), wpb[LAYERS], None, nxt, 3, res=gout, math=math, center_cin=ctr)
     K.TIMER_TAG = ""
@@ -487,18 +505,18 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
     dlogits = _new(dev, B, H, W, g.Tp)
     K.tsum_backward(dweighted, dgap_pix, sv.aligned, sv.attn, T, F, daligned, dlogits)
     pre = "temporal_aggregator.attention."
-    _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", ws, 3, math=math)
+    _wgrad(Sl(sv.a2), F, Sl(dlogits, T), G, pre + "4.weight", pre + "4.bias", wq, 3, math=math)
     da2 = _new(dev, B, H, W, F, dtype=act_dtype)
     K.conv_forward(Sl(dlogits), packs.get(pre + "4.weight", True, g.Tp, F), None, Sl(da2), 3,
                    mask=Sl(sv.a2), mask_c0=0, mask_c1=F, math=math)
-    _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", ws, 3, math=math)
+    _wgrad(Sl(sv.a1), F, Sl(da2), G, pre + "2.weight", pre + "2.bias", wq, 3, math=math)
     da1 = _new(dev, B, H, W, F, dtype=act_dtype)
     if sv.a1_bits is not None:
         K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3, math=math, bits=sv.a1_bits, bits_mode=2)
     else:
         K.conv_forward(Sl(da2), packs.get(pre + "2.weight", True, F, F), None, Sl(da1), 3,
                        mask=Sl(sv.a1), mask_c0=0, mask_c1=F, math=math)
-    _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", ws, 3, math=math)
+    _wgrad(Sl(sv.aligned), T * F, Sl(da1), G, pre + "0.weight", pre + "0.bias", wq, 3, math=math)
     K.conv_forward(Sl(da1), packs.get(pre + "0.weight", True, F, T * F), None, Sl(daligned), 3,
                    accumulate=True, math=math)
     if not feat16:
@@ -524,7 +542,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             x_t = acts[li]
             name = f"motion_estimator.flow_net.{idx}."
             x_sl = Sl(x_t) if li > 0 else Sl(x_t, CORR_LD, 0)
-            _wgrad(x_sl, chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", ws, 3, math=math)
+            _wgrad(x_sl, chans[li], Sl(dy_t, dy_c), G, name + "weight", name + "bias", wq, 3, math=math)
             cin_store = dy_t.shape[-1]
             wp = packs.get(name + "weight", True, cin_store, chans[li])
             dx_t = _new(dev, NO, H, W, x_t.shape[-1], dtype=act_dtype if li > 0 else x_t.dtype)
@@ -584,7 +602,7 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
             dp = _new(dev, NI, H, W, F, dtype=act_dtype)
             K.bn_relu_backward(dcur, sv.pws[k], B, sv.bn_mean[k], sv.bn_invstd[k], P[pre + "bn.weight"],
                                P[pre + "bn.bias"], sv.training, dp, G[pre + "bn.weight"], G[pre + "bn.bias"], ws)
-            _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, ws, 1, math=math)
+            _wgrad(Sl(sv.dws[k]), F, Sl(dp), G, pre + "pointwise.weight", None, wq, 1, math=math)
             K.conv_forward(Sl(dp), K.conv_pack(P[pre + "pointwise.weight"], True, F, F, math=math), None, Sl(dd), 1, math=math)
         xin, xin_bn = sv.dw_in[k]
         if fused_bwd and k > 0 and xin.dtype == torch.bfloat16 and os.environ.get("NVQ_FUSED_DW_BWD", "1") != "0":
@@ -619,12 +637,13 @@ def backward(P: Dict[str, torch.Tensor], sv: Saved, dout: torch.Tensor, G: Dict[
         # the skip path of  feat = body(h) + h  is summed inside the head kernel (dout2)
         K.head_wgrad(sv.frames, g.slots, dcur, sv.feat0, G["feature_extractor.head.0.weight"],
                      G["feature_extractor.head.0.bias"], ws, dout2=dfeat_all)
+    if small:
+        wq.flush()
 
 
 # ----------------------------------------------------------------------------- LightweightSuperResolution
 LIGHT_F = 32
 LIGHT_BLOCKS = (2, 3, 4, 5)       # indices of the DepthwiseSeparableConv modules inside `net`
-
 
 def light_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, scale: int, training: bool, math: int = K.MATH_F32,
                   act_dtype: torch.dtype = torch.float32) -> "tuple[torch.Tensor, Saved]":

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader, TensorDataset
 
-from _common import compute_psnr, pick_device, shard
+from _common import compute_psnr, make_optimizer, pick_device, shard
 from nerve_cl import ops, parallel
 from nerve_cl.models import SuperResolutionNet
 
@@ -43,7 +43,7 @@ def train(args) -> None:
     if world > 1:
         parallel.enable_data_parallel(model)
     say(f"  Parameters: {sum(p.numel() for p in model.parameters()):,}")
-    optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=1e-5)
+    optimizer = make_optimizer(torch.optim.AdamW, model.parameters(), lr=args.lr, weight_decay=1e-5)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epochs)
     criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader, TensorDataset
 
-from _common import pick_device, shard
+from _common import make_optimizer, pick_device, shard
 from nerve_cl import ops, parallel
 from nerve_cl.continual import EWC, EpisodicMemory, FOMAML, ContinualDistillation  # noqa: F401
 from nerve_cl.models import EnhancementConfig, EnhancementEngine
@@ -56,7 +56,7 @@ def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
     device = next(model.parameters()).device
     adapter = _ClipAdapter(model)
     ewc = EWC(adapter, ewc_lambda=config.get("ewc_lambda", 5000))
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    optimizer = make_optimizer(torch.optim.Adam, model.parameters(), lr=1e-4)
     criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
     say = print if rank == 0 else (lambda *a, **k: None)
     for task_id, (task_name, (lr, hr)) in enumerate(tasks):
@@ -84,7 +84,7 @@ def train_with_ewc(model, tasks, config, rank=0, world=1, epochs=5):
 
 def train_with_replay(model, tasks, memory, config, rank=0, epochs=5):
     device = next(model.parameters()).device
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    optimizer = make_optimizer(torch.optim.Adam, model.parameters(), lr=1e-4)
     criterion = ops.MSELoss()       # nn.MSELoss() of the reference, as libnvq kernels
     say = print if rank == 0 else (lambda *a, **k: None)
     for task_id, (task_name, (lr, hr)) in enumerate(tasks):

@@ -23,7 +23,7 @@ for precision, graphs in MODES:
         TC.configure_precision(model, precision, graphs)
         adapter = TC._ClipAdapter(model)
         ewc = EWC(adapter, ewc_lambda=5000)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        opt = TC.make_optimizer(torch.optim.Adam, model.parameters(), lr=1e-4)     # as train_with_ewc does
         crit = ops.MSELoss()
         lr, hr = TC.create_task_data("sports", 64)
         lr, hr = lr.to(dev), hr.to(dev)
