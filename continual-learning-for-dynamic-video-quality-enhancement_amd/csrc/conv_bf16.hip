@@ -406,10 +406,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_bf16_kernel(con
         // full 32 / 64-channel bf16 outputs: stage the tile's output in LDS and store whole pixel rows (64 / 128 B)
         constexpr int PPP = NT / 8;                          // 16-byte pieces per pixel
         const bool can_stage = d.out_bf16 && vec_ok && (CS == 2 || d.cout_store - cz * NT >= NT);   // workgroup-uniform
-        if (can_stage) __syncthreads();                      // every wave is done reading xs / ws
+        // "every wave is done reading xs / ws": the barrier sits inside the epilogue, behind its operand loads
+        if (can_stage && !(d.cout_store - cz * NT >= NT)) __syncthreads();   // (CS = 2: a half that stores nothing)
         if (can_stage && d.cout_store - cz * NT >= NT) {     // (CS = 2: per half of the workgroup)
             __bf16* stage = lds + (tid >> 6) * (2 * TW * SPX);
-            conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage, SPX);
+            conv_epilogue<NB>(d, acc, n, ty, tx, cz, wave, c, g, vec_ok, TH_, stage, SPX, true);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __bf16* o16 = reinterpret_cast<__bf16*>(d.out);

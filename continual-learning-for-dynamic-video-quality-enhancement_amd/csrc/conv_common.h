@@ -113,10 +113,14 @@ __device__ __forceinline__ float4 raw4_f(raw4 r, int is_bf16) {
 
 // FULL: bias, ReLU bits and the residual of all four pixel blocks are in flight before the first use (needs the registers:
 // 4 NB + 16 NB); otherwise, like the mask always, they are loaded per (pixel block, channel block).
+// barrier: a workgroup barrier between the operand loads and the first write to `stage` - the caller's "every wave is done with
+// the K loop's LDS images" barrier, placed here so that the loads are in flight while the waves wait for each other (a tile's
+// last barrier costs wave 0 several microseconds: tools/tile_timeline.py).  Every thread of the workgroup must then make this
+// call, or a __syncthreads() of its own in its place.
 template <int NB, bool FULL = (NB <= 2)>
 __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&acc)[NB][4], int n, int ty, int tx,
                                               int cz, int wave, int c, int g, int vec_ok, int th = TH,
-                                              __bf16* stage = nullptr, int stage_px = STAGE_PX) {
+                                              __bf16* stage = nullptr, int stage_px = STAGE_PX, bool barrier = false) {
     constexpr int NT = NB * 16;
     const int H = d.h, W = d.w;
     if (vec_ok) {
@@ -165,6 +169,7 @@ __device__ __forceinline__ void conv_epilogue(const nvq_conv_desc& d, f32x4 (&ac
                 for (int pb = 0; pb < 4; ++pb) res_load(pb, 0, pb);
             }
         }
+        if (barrier) __syncthreads();
         // ---- phase 2: arithmetic and stores
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
