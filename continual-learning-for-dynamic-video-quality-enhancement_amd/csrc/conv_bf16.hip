@@ -1186,6 +1186,12 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
                            g_debug_mode & 3, TailArgs{});
         return check_launch("conv_forward_bf16");
     }
+    // tile_rows 264: the same layers on v_mfma_f32_32x32x16_bf16, a wave = 2 rows x all 64 channels (conv_m32.hip; A/B only)
+    if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows == 264) {
+        NVQ_REQUIRE(vec_ok && d.out_bf16 && d.cout_store % 64 == 0 && d.cin % 8 == 0,
+                    "conv_forward: tile_rows 264 needs bf16 output and a multiple of 64 stored channels");
+        return conv_forward_m32(d, 64, g_debug_mode & 3, s);
+    }
     // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
     if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows != 8) {
         const dim3 grid8((unsigned)((long)tilesX * tilesY * d.n), ncz);

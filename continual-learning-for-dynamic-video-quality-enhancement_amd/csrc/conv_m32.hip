@@ -25,14 +25,16 @@ constexpr int XS32 = 40;   // bf16 per staged pixel
 // Epilogue (vector path only; the host sends everything else to conv_bf16_kernel).  acc[r] is the 32x32 result with
 // M = output channel, N = pixel: lane (x = lane & 31, h = lane >> 5) holds channels 8 j + 4 h .. + 3 (j = 0..3, registers
 // 4 j .. 4 j + 3) of pixel (row0 + r, gx).  Same arithmetic, in the same order, as conv_epilogue (conv_common.h).
-// stage != nullptr: the value goes as bf16 into the wave's [R x 32 px][STAGE_PX] LDS tile instead of global memory.
+// stage != nullptr: the value goes as bf16 into the wave's [R x 32 px][stage_px] LDS tile instead of global memory.
+// cbase: first of the fragment's 32 output channels (the 64-channel kernel calls twice); stage_c0: channel 0 of the staging tile.
 // bias_lds: the 32 bias values as the workgroup put them into LDS at its entry (zero beyond cout), read instead of d.bias;
 // bits_pre: the pixels' ReLU-mask words (bits_mode 2) as loaded at the workgroup's entry - either spares the tile's tail a
 // memory round trip (~1.5 us for the cached bias, 2-4 us for the mask words, of ~25 us per tile: tools/tile_timeline.py).
 template <int R>
 __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16 (&acc)[R], int n, int row0, int gx, int x,
                                                   int h, __bf16* stage, const float* bias_lds = nullptr,
-                                                  const unsigned* bits_pre = nullptr) {
+                                                  const unsigned* bits_pre = nullptr, int cbase = 0, int stage_c0 = 0,
+                                                  int stage_px = STAGE_PX) {
     const int H = d.h, W = d.w;
     bool okp[R];
     size_t pixv[R];
@@ -43,7 +45,8 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
     }
     int cov[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cov[j] = 8 * j + 4 * h;
+    for (int j = 0; j < 4; ++j) cov[j] = cbase + 8 * j + 4 * h;
+    const int wsel = cbase >> 5;                          // the fragment's word of a pixel's bits_words mask words
     // ---- phase 1: every operand load back to back (see conv_epilogue)
     float4 bias4[4];
     unsigned bits_in[R];
@@ -51,12 +54,12 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
     const int bw = d.bits_words > 0 ? d.bits_words : 1;
     if (d.bits_mode == 2) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) bits_in[r] = bits_pre ? bits_pre[r] : d.bits[pixv[r] * bw];
+        for (int r = 0; r < R; ++r) bits_in[r] = bits_pre ? bits_pre[r] : d.bits[pixv[r] * bw + wsel];
     }
     if (d.bias) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            bias4[j] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + cov[j]) : ld4(d.bias + (cov[j] < d.cout ? cov[j] : 0));
+            bias4[j] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + cov[j] - cbase) : ld4(d.bias + (cov[j] < d.cout ? cov[j] : 0));
     }
     if (d.res) {
 #pragma unroll
@@ -113,20 +116,20 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
             if (d.bits_mode == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (!((bits_in[r] >> (co + e)) & 1u)) v[e] = 0.f;
+                    if (!((bits_in[r] >> ((co & 31) + e)) & 1u)) v[e] = 0.f;
             } else if (d.bits_mode == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << (co + e);
+                for (int e = 0; e < 4; ++e) bits_out |= (v[e] > 0.f ? 1u : 0u) << ((co & 31) + e);
             }
             if (stage)
-                *reinterpret_cast<bf16x4*>(stage + (r * TW + x) * STAGE_PX + co) =
+                *reinterpret_cast<bf16x4*>(stage + (r * TW + x) * stage_px + co - stage_c0) =
                     (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             else
                 stx4(d.out, oi, d.out_bf16, make_float4(v[0], v[1], v[2], v[3]));
         }
         if (d.bits_mode == 1) {                           // OR over the two lanes of this pixel, lane h = 0 stores the word
             bits_out |= __shfl_xor(bits_out, 32, 64);
-            if (h == 0) d.bits[pix * bw] = bits_out;
+            if (h == 0) d.bits[pix * bw + wsel] = bits_out;
         }
     }
 }
@@ -408,7 +411,196 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
     conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, nullptr, biasL, bits_pre);
 }
 
-// variant: 2 = two rows per wave, 8 waves; 4 = four rows per wave, 4 waves (fragments read one group ahead)
+// 64 output channels per workgroup (cout >= 64: attention, flow net, upsampler, the blocks' input-gradient conv): 8 x 32-pixel
+// tiles, four waves, a wave = 2 rows x 32 pixels x BOTH 32-channel fragments (64 accumulators), so every pixel fragment read
+// feeds two MFMAs and every weight fragment two rows - against the shipped channel-split kernel (conv_bf16_kernel<2,3,true,8,2>:
+// eight waves, each 32 of the 64 channels, the pixel fragments read by both halves).  blockIdx.y = the 64-channel slab.
+// Measured slower (profiles/r04_wide_conv_m32.txt: two waves per SIMD), kept behind tile_rows = 264 for the A/B.
+__global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc, int dbg) {
+    constexpr int R = 2, NW = 4, NCO = 2, NT = 64, KS = 3, TAPS = 9;
+    constexpr int NTHR = 64 * NW;
+    constexpr int TH_ = R * NW;
+    constexpr int HW_ = TW + 2, HH_ = TH_ + 2, NPIX = HW_ * HH_;
+    constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);
+    constexpr int XITEMS = NPIX * 4;
+    constexpr int XPER = (XITEMS + NTHR - 1) / NTHR;
+    constexpr int WPIECES = TAPS * 4 * NT;
+    constexpr int WPER = (WPIECES + NTHR - 1) / NTHR;
+    constexpr int CT_K = (TAPS / 2) * 4 * NT / NTHR;
+    constexpr int CT_N = 4 * NT;
+    static_assert(((TAPS / 2) * 4 * NT) % NTHR == 0 && CT_N <= NTHR && WPIECES % NTHR == 0, "weight pieces per thread");
+    static_assert(NW * R * TW * STAGE_PX64 <= NPIX * XS32 + WS_HALFS, "the output staging tiles fit the LDS stages");
+
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XS32 + WS_HALFS];
+    __bf16* xs = lds;
+    __bf16* ws = lds + NPIX * XS32;
+    const int kcl = d.center_cin / KCB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 31;
+    const int h = lane >> 5;
+    const int cz = blockIdx.y;
+
+    int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bt % tilesX; bt /= tilesX;
+    const int ty = bt % tilesY;
+    const int n = bt / tilesY;
+    const int H = d.h, W = d.w;
+
+    f32x16 acc[NCO][R];
+#pragma unroll
+    for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][r][e] = 0.f;
+
+    const __bf16* wp_base = reinterpret_cast<const __bf16*>(d.wpack) + (size_t)cz * nkc * WS_HALFS;
+    const __bf16* in16 = reinterpret_cast<const __bf16*>(d.in) + d.in_coff;
+    unsigned xoff[XPER];
+    bool xok[XPER];
+#pragma unroll
+    for (int k = 0; k < XPER; ++k) {
+        const int item = tid + k * NTHR;
+        const int hp = item >> 2;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int gy = ty * TH_ + hy - 1, gx = tx * TW + hx - 1;
+        xok[k] = item < XITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xoff[k] = xok[k] ? (unsigned)(((size_t)(n * H + gy) * W + gx) * (d.in_plane ? 32 : d.in_ld)) : 0u;
+    }
+    const int nk0 = d.in_plane ? d.in_ld >> 5 : 0x7fffffff;
+    const int sh0 = d.in_plane ? __ffs(d.in_ld >> 5) - 1 : 0;
+    const int chg = 8 * (tid & 3);
+    u32x4 xr[XPER];
+    u32x4 wr[WPER];
+    bool cv0 = false;
+    auto fetch = [&](int kc, bool light) {
+        const int ch = kc * KCB + chg;
+        cv0 = ch < d.cin;
+        const bool lead = kc < nk0;
+        const int sh = lead ? sh0 : 0;
+        const unsigned cbase = lead ? (unsigned)kc * KCB : (unsigned)kc * d.in_plane;
+        const unsigned o0 = cv0 ? cbase + chg : 0u;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
+        if (light) {
+            wr[CT_K] = wsrc[tid + CT_K * NTHR];
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * NTHR];
+        }
+    };
+    auto commit = [&](bool light) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int item = tid + k * NTHR;
+            if (item < XITEMS)
+                *reinterpret_cast<u32x4*>(xs + (item >> 2) * XS32 + 8 * (item & 3)) = (xok[k] && cv0) ? xr[k] : z;
+        }
+        if (light) {
+            reinterpret_cast<u32x4*>(ws)[tid + CT_K * NTHR] = wr[CT_K];
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * NTHR] = wr[k];
+        }
+    };
+    const __bf16* xrow = xs + (R * wave * HW_ + x) * XS32 + 8 * h;
+    const __bf16* wfrag = ws + (h * NT + x) * 8;
+    auto ldB = [&](int rr, int dx, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(xrow + (rr * HW_ + dx) * XS32 + 16 * ks);
+    };
+    auto ldA = [&](int tap, int ks, int cb) -> bf16x8 {       // slab [tap][g = 2 ks + h][64 channels][8]
+        return *reinterpret_cast<const bf16x8*>(wfrag + ((tap * 4 + 2 * ks) * NT + cb * 32) * 8);
+    };
+    auto stage_chunk = [&](int kc, bool cl, bool fl) {
+        __syncthreads();
+        commit(cl);
+        __syncthreads();
+        if (kc + 1 < nkc && !(dbg & 2)) fetch(kc + 1, fl);
+    };
+    auto center_stage = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[NCO], b[R];
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb) a[cb] = ldA(TAPS / 2, ks, cb);
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = ldB(r + 1, 1, ks);
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[cb][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[r], acc[cb][r], 0, 0, 0);
+        }
+    };
+
+    int kc = 0;
+    if (kcl > 0) {
+        fetch(0, true);
+        for (; kc + 1 < kcl; ++kc) {
+            stage_chunk(kc, true, true);
+            if (!(dbg & 1)) center_stage();
+        }
+        stage_chunk(kc, true, false);
+        if (!(dbg & 1)) center_stage();
+        ++kc;
+    } else {
+        fetch(0, false);
+    }
+    for (; kc < nkc; ++kc) {
+        stage_chunk(kc, false, false);
+        if (dbg & 1) continue;
+        // six groups (k-step, dx): R + 2 pixel fragments, 3 x NCO weight fragments, 3 R NCO MFMAs
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) {
+            const int ks = gi / 3, dx = gi % 3;
+            bf16x8 b[R + 2], a[3][NCO];
+#pragma unroll
+            for (int rr = 0; rr < R + 2; ++rr) b[rr] = ldB(rr, dx, ks);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int cb = 0; cb < NCO; ++cb) a[dy][cb] = ldA(dy * KS + dx, ks, cb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int cb = 0; cb < NCO; ++cb)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[cb][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][cb], b[r + dy], acc[cb][r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: both fragments through the wave's LDS staging tile [R x 32 px][64 channels], whole 128-byte pixel rows out
+    // (host: bf16 output, all 64 channels of the slab stored)
+    const int row0 = ty * TH_ + R * wave, gx = tx * TW + x;
+    __syncthreads();                                          // every wave is done reading xs / ws
+    __bf16* stage = lds + wave * (R * TW * STAGE_PX64);
+#pragma unroll
+    for (int cb = 0; cb < NCO; ++cb)
+        conv_epilogue_m32<R>(d, acc[cb], n, row0, gx, x, h, stage, nullptr, nullptr, cz * NT + cb * 32, cz * NT, STAGE_PX64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
+#pragma unroll
+    for (int k = 0; k < 4 * R; ++k) {
+        const int item = lane + k * 64;
+        const int px = item >> 3, piece = item & 7;           // wave-local pixel (R rows x 32), 8-channel piece of 64
+        const int gy = row0 + (px >> 5), gxx = tx * TW + (px & 31);
+        if (gy < H && gxx < W)
+            *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gxx) * d.out_ld + d.out_coff + cz * NT + 8 * piece) =
+                *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX64 + 8 * piece);
+    }
+}
+
+// variant: 2 = two rows per wave, 8 waves; 4 = four rows per wave, 4 waves (fragments read one group ahead); 64 = the
+// 64-channel-per-workgroup kernel
 int conv_forward_m32(const nvq_conv_desc& d, int variant, int dbg, hipStream_t s) {
     NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32),
                 "conv_forward(bf16, 32x32x16): input tensor of %d x %d x %d x %d elements exceeds the 32-bit offsets of the kernels",
@@ -416,7 +608,11 @@ int conv_forward_m32(const nvq_conv_desc& d, int variant, int dbg, hipStream_t s
     const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + 15) / 16;
     const int nkc = (d.cin + KCB - 1) / KCB;
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n));
-    if (variant == 2)
+    if (variant == 64) {                                      // 64 output channels per workgroup, 8 x 32 tiles (the caller checks)
+        const int tY8 = (d.h + 7) / 8;
+        hipLaunchKernelGGL(conv_m32w_kernel, dim3((unsigned)((long)tilesX * tY8 * d.n), (d.cout_store + 63) / 64), dim3(256), 0, s, d,
+                           tilesX, tY8, nkc, dbg);
+    } else if (variant == 2)
         hipLaunchKernelGGL((conv_m32_kernel<2, 8, false>), grid, dim3(512), 0, s, d, tilesX, tilesY, nkc, dbg);
     else
         hipLaunchKernelGGL((conv_m32_kernel<4, 4, true>), grid, dim3(256), 0, s, d, tilesX, tilesY, nkc, dbg);

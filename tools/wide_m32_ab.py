@@ -1,0 +1,39 @@
+"""GPU box: the cout >= 64 3x3 layers of the step on the shipped channel-split kernel (conv_bf16_kernel<2,3,true,8,2>, 16x16x32
+MFMA) against conv_m32w_kernel (tile_rows 264: a wave = 2 rows x 64 channels on 32x32x16), 540 x 960, bf16 tensors, bias + ReLU -
+the six shapes of profiles/r03_wide_conv_16_wave_tiles.txt."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "continual-learning-for-dynamic-video-quality-enhancement_amd"))
+import torch
+from nerve_cl import _nvq as K
+
+H, W = 540, 960
+REPS = int(os.environ.get("AB_REPS", 10))
+dev = torch.device("cuda")
+torch.manual_seed(0)
+
+def timeit(fn, n=REPS):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+print(" cin -> cout  images   channel-split 16x16x32      64-channel waves 32x32x16     max |diff|")
+for cin, cout, N in ((96, 128, 16), (128, 64, 16), (64, 128, 16), (224, 64, 8), (192, 64, 8), (64, 64, 8)):
+    x = torch.randn(N, H, W, cin, device=dev).clamp_(-3, 3).to(torch.bfloat16)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    b = torch.randn(cout, device=dev) * 0.1
+    wp = K.conv_pack(w, False, cin, math=K.MATH_BF16)
+    res, outs = {}, {}
+    for rows in (0, 264, 0, 264):
+        out = torch.zeros(N, H, W, cout, device=dev, dtype=torch.bfloat16)
+        ms = timeit(lambda: K.conv_forward(K.Sl(x), wp, b, K.Sl(out), 3, relu=True, math=K.MATH_BF16, tile_rows=rows))
+        res[rows] = min(res.get(rows, 1e9), ms)
+        outs[rows] = out
+    fl = 2.0 * N * H * W * cin * cout * 9
+    d = (outs[0].float() - outs[264].float()).abs().max().item()
+    print(f"{cin:4d} -> {cout:4d}   {N:3d}     {res[0]:6.3f} ms {fl / res[0] / 1e9:5.0f} TFLOP/s      {res[264]:6.3f} ms {fl / res[264] / 1e9:5.0f} TFLOP/s      {d:.3g}",
+          flush=True)
