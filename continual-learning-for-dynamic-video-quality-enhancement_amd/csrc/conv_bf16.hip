@@ -1187,10 +1187,11 @@ int conv_forward_bf16(const nvq_conv_desc& d, int vec_ok, hipStream_t s) {
         return check_launch("conv_forward_bf16");
     }
     // tile_rows 264: the same layers on v_mfma_f32_32x32x16_bf16, a wave = 2 rows x all 64 channels (conv_m32.hip; A/B only)
-    if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows == 264) {
+    // (265: the channel split itself on 32x32x16, eight waves)
+    if (d.ksize == 3 && NT == 64 && d.in_bf16 && (d.tile_rows == 264 || d.tile_rows == 265)) {
         NVQ_REQUIRE(vec_ok && d.out_bf16 && d.cout_store % 64 == 0 && d.cin % 8 == 0,
-                    "conv_forward: tile_rows 264 needs bf16 output and a multiple of 64 stored channels");
-        return conv_forward_m32(d, 64, g_debug_mode & 3, s);
+                    "conv_forward: tile_rows 264 / 265 need bf16 output and a multiple of 64 stored channels");
+        return conv_forward_m32(d, d.tile_rows == 264 ? 64 : 65, g_debug_mode & 3, s);
     }
     // 64 output channels per workgroup, 3x3, bf16 input: eight waves, each half of them 32 of the channels (see the kernel)
     if (d.ksize == 3 && NT == 64 && d.in_bf16 && d.tile_rows != 8) {

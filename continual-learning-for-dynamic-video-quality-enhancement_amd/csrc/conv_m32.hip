@@ -30,7 +30,9 @@ constexpr int XS32 = 40;   // bf16 per staged pixel
 // bias_lds: the 32 bias values as the workgroup put them into LDS at its entry (zero beyond cout), read instead of d.bias;
 // bits_pre: the pixels' ReLU-mask words (bits_mode 2) as loaded at the workgroup's entry - either spares the tile's tail a
 // memory round trip (~1.5 us for the cached bias, 2-4 us for the mask words, of ~25 us per tile: tools/tile_timeline.py).
-template <int R>
+// FULL = false: the residual is loaded per (row, channel group) where it is used (4 registers instead of 16 R), for kernels
+// at the 128-register budget whose epilogue would otherwise spill.
+template <int R, bool FULL = true>
 __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16 (&acc)[R], int n, int row0, int gx, int x,
                                                   int h, __bf16* stage, const float* bias_lds = nullptr,
                                                   const unsigned* bits_pre = nullptr, int cbase = 0, int stage_c0 = 0,
@@ -50,7 +52,7 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
     // ---- phase 1: every operand load back to back (see conv_epilogue)
     float4 bias4[4];
     unsigned bits_in[R];
-    raw4 res4[4][R];
+    raw4 res4[FULL ? 4 : 1][FULL ? R : 1];
     const int bw = d.bits_words > 0 ? d.bits_words : 1;
     if (d.bits_mode == 2) {
 #pragma unroll
@@ -61,12 +63,14 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
         for (int j = 0; j < 4; ++j)
             bias4[j] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + cov[j] - cbase) : ld4(d.bias + (cov[j] < d.cout ? cov[j] : 0));
     }
-    if (d.res) {
+    if constexpr (FULL) {
+        if (d.res) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                res4[j][r] = ld_raw4(d.res, pixv[r] * d.res_ld + d.res_coff + (cov[j] < d.res_cmax ? cov[j] : 0), d.res_bf16);
+                for (int j = 0; j < 4; ++j)
+                    res4[j][r] = ld_raw4(d.res, pixv[r] * d.res_ld + d.res_coff + (cov[j] < d.res_cmax ? cov[j] : 0), d.res_bf16);
+        }
     }
     // ---- phase 2: arithmetic and stores
 #pragma unroll
@@ -98,7 +102,8 @@ __device__ __forceinline__ void conv_epilogue_m32(const nvq_conv_desc& d, f32x16
             for (int e = 0; e < 4; ++e) v[e] *= d.alpha;
             if (d.out2) stx4(d.out2, pix * d.out2_ld + d.out2_coff + co, d.out2_bf16, make_float4(v[0], v[1], v[2], v[3]));
             if (d.res && co < d.res_cmax) {
-                const float4 q = raw4_f(res4[j][r], d.res_bf16);
+                if constexpr (!FULL) res4[0][0] = ld_raw4(d.res, pix * d.res_ld + d.res_coff + co, d.res_bf16);
+                const float4 q = raw4_f(res4[FULL ? j : 0][FULL ? r : 0], d.res_bf16);
                 v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
             }
             const size_t oi = pix * d.out_ld + d.out_coff + co;
@@ -411,15 +416,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32_kernel(cons
     conv_epilogue_m32<R>(d, acc, n, row0, gx, x, h, nullptr, biasL, bits_pre);
 }
 
-// 64 output channels per workgroup (cout >= 64: attention, flow net, upsampler, the blocks' input-gradient conv): 8 x 32-pixel
-// tiles, four waves, a wave = 2 rows x 32 pixels x BOTH 32-channel fragments (64 accumulators), so every pixel fragment read
-// feeds two MFMAs and every weight fragment two rows - against the shipped channel-split kernel (conv_bf16_kernel<2,3,true,8,2>:
-// eight waves, each 32 of the 64 channels, the pixel fragments read by both halves).  blockIdx.y = the 64-channel slab.
-// Measured slower (profiles/r04_wide_conv_m32.txt: two waves per SIMD), kept behind tile_rows = 264 for the A/B.
-__global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc, int dbg) {
-    constexpr int R = 2, NW = 4, NCO = 2, NT = 64, KS = 3, TAPS = 9;
+// 64 output channels per workgroup (cout >= 64: attention, flow net, upsampler, the blocks' input-gradient conv) on 8 x 32-pixel
+// tiles, against the shipped channel-split kernel (conv_bf16_kernel<2,3,true,8,2>, 16x16x32 MFMA).  blockIdx.y = the 64-channel slab.
+//   NW = 4, NCO = 2 (tile_rows 264): a wave = 2 rows x 32 pixels x BOTH 32-channel fragments (64 accumulators), every pixel
+//                   fragment read feeds two MFMAs and every weight fragment two rows; 190 VGPRs, two waves per SIMD;
+//   NW = 8, NCO = 1 (tile_rows 265): the channel split itself on 32x32x16 - wave = (row pair wave & 3, channel half wave >> 2),
+//                   32 accumulators, four waves per SIMD, half the MFMA instructions of the shipped kernel.
+// Measured: profiles/r04_wide_conv_m32.txt.
+template <int NW, int NCO>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void conv_m32w_kernel(const nvq_conv_desc d, int tilesX, int tilesY, int nkc,
+                                                                             int dbg) {
+    constexpr int R = 2, NT = 64, KS = 3, TAPS = 9;
+    static_assert((NW == 4 && NCO == 2) || (NW == 8 && NCO == 1), "64 channels x 8 rows per workgroup");
     constexpr int NTHR = 64 * NW;
-    constexpr int TH_ = R * NW;
+    constexpr int TH_ = 8;
+    constexpr int SPXW = NCO == 2 ? STAGE_PX64 : STAGE_PX;    // halfs per pixel of a wave's staging tile
     constexpr int HW_ = TW + 2, HH_ = TH_ + 2, NPIX = HW_ * HH_;
     constexpr int WS_HALFS = ws_stride_halfs(TAPS, NT);
     constexpr int XITEMS = NPIX * 4;
@@ -428,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d
     constexpr int WPER = (WPIECES + NTHR - 1) / NTHR;
     constexpr int CT_K = (TAPS / 2) * 4 * NT / NTHR;
     constexpr int CT_N = 4 * NT;
-    static_assert(((TAPS / 2) * 4 * NT) % NTHR == 0 && CT_N <= NTHR && WPIECES % NTHR == 0, "weight pieces per thread");
-    static_assert(NW * R * TW * STAGE_PX64 <= NPIX * XS32 + WS_HALFS, "the output staging tiles fit the LDS stages");
+    static_assert(((TAPS / 2) * 4 * NT) % NTHR == 0 && CT_N <= NTHR, "the centre tap starts a piece row");
+    static_assert(NW * R * TW * SPXW <= NPIX * XS32 + WS_HALFS, "the output staging tiles fit the LDS stages");
 
     __shared__ __attribute__((aligned(16))) __bf16 lds[NPIX * XS32 + WS_HALFS];
     __bf16* xs = lds;
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d
     const int x = lane & 31;
     const int h = lane >> 5;
     const int cz = blockIdx.y;
+    const int rp = wave & 3, half = NCO == 2 ? 0 : wave >> 2;   // the wave's row pair; its 32-channel half (channel split)
 
     int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = bt % tilesX; bt /= tilesX;
@@ -487,10 +499,10 @@ __global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d
         for (int k = 0; k < XPER; ++k) xr[k] = *reinterpret_cast<const u32x4*>(in16 + ((xoff[k] << sh) + o0));
         const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp_base + (size_t)kc * WS_HALFS);
         if (light) {
-            wr[CT_K] = wsrc[tid + CT_K * NTHR];
+            wr[CT_K] = wsrc[(tid < CT_N ? tid : 0) + CT_K * NTHR];
         } else {
 #pragma unroll
-            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * NTHR];
+            for (int k = 0; k < WPER; ++k) wr[k] = wsrc[tid + k * NTHR < WPIECES ? tid + k * NTHR : 0];
         }
     };
     auto commit = [&](bool light) {
@@ -502,14 +514,15 @@ __global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d
                 *reinterpret_cast<u32x4*>(xs + (item >> 2) * XS32 + 8 * (item & 3)) = (xok[k] && cv0) ? xr[k] : z;
         }
         if (light) {
-            reinterpret_cast<u32x4*>(ws)[tid + CT_K * NTHR] = wr[CT_K];
+            if (tid < CT_N) reinterpret_cast<u32x4*>(ws)[tid + CT_K * NTHR] = wr[CT_K];
         } else {
 #pragma unroll
-            for (int k = 0; k < WPER; ++k) reinterpret_cast<u32x4*>(ws)[tid + k * NTHR] = wr[k];
+            for (int k = 0; k < WPER; ++k)
+                if ((k + 1) * NTHR <= WPIECES || tid + k * NTHR < WPIECES) reinterpret_cast<u32x4*>(ws)[tid + k * NTHR] = wr[k];
         }
     };
-    const __bf16* xrow = xs + (R * wave * HW_ + x) * XS32 + 8 * h;
-    const __bf16* wfrag = ws + (h * NT + x) * 8;
+    const __bf16* xrow = xs + (R * rp * HW_ + x) * XS32 + 8 * h;
+    const __bf16* wfrag = ws + (h * NT + half * 32 + x) * 8;
     auto ldB = [&](int rr, int dx, int ks) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(xrow + (rr * HW_ + dx) * XS32 + 16 * ks);
     };
@@ -577,30 +590,32 @@ __global__ __launch_bounds__(256, 2) void conv_m32w_kernel(const nvq_conv_desc d
         }
     }
 
-    // epilogue: both fragments through the wave's LDS staging tile [R x 32 px][64 channels], whole 128-byte pixel rows out
-    // (host: bf16 output, all 64 channels of the slab stored)
-    const int row0 = ty * TH_ + R * wave, gx = tx * TW + x;
+    // epilogue: the wave's fragment(s) through its LDS staging tile [R x 32 px][32 NCO channels], whole 64 / 128-byte pixel rows
+    // out (host: bf16 output, all 64 channels of the slab stored)
+    const int row0 = ty * TH_ + R * rp, gx = tx * TW + x;
+    const int c0 = cz * NT + half * 32;                       // first channel of the wave's staging tile
     __syncthreads();                                          // every wave is done reading xs / ws
-    __bf16* stage = lds + wave * (R * TW * STAGE_PX64);
+    __bf16* stage = lds + wave * (R * TW * SPXW);
 #pragma unroll
     for (int cb = 0; cb < NCO; ++cb)
-        conv_epilogue_m32<R>(d, acc[cb], n, row0, gx, x, h, stage, nullptr, nullptr, cz * NT + cb * 32, cz * NT, STAGE_PX64);
+        conv_epilogue_m32<R, NW == 4>(d, acc[cb], n, row0, gx, x, h, stage, nullptr, nullptr, c0 + cb * 32, c0, SPXW);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __bf16* o16 = reinterpret_cast<__bf16*>(d.out);
+    constexpr int PPP = 4 * NCO;                              // 16-byte pieces per pixel of the wave's channels
 #pragma unroll
-    for (int k = 0; k < 4 * R; ++k) {
+    for (int k = 0; k < R * TW * PPP / 64; ++k) {
         const int item = lane + k * 64;
-        const int px = item >> 3, piece = item & 7;           // wave-local pixel (R rows x 32), 8-channel piece of 64
+        const int px = item / PPP, piece = item % PPP;        // wave-local pixel (R rows x 32)
         const int gy = row0 + (px >> 5), gxx = tx * TW + (px & 31);
         if (gy < H && gxx < W)
-            *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gxx) * d.out_ld + d.out_coff + cz * NT + 8 * piece) =
-                *reinterpret_cast<const u32x4*>(stage + px * STAGE_PX64 + 8 * piece);
+            *reinterpret_cast<u32x4*>(o16 + ((size_t)(n * H + gy) * W + gxx) * d.out_ld + d.out_coff + c0 + 8 * piece) =
+                *reinterpret_cast<const u32x4*>(stage + px * SPXW + 8 * piece);
     }
 }
 
-// variant: 2 = two rows per wave, 8 waves; 4 = four rows per wave, 4 waves (fragments read one group ahead); 64 = the
-// 64-channel-per-workgroup kernel
+// variant: 2 = two rows per wave, 8 waves; 4 = four rows per wave, 4 waves (fragments read one group ahead); 64 / 65 = the
+// 64-channel-per-workgroup kernels (whole-slab waves / channel split)
 int conv_forward_m32(const nvq_conv_desc& d, int variant, int dbg, hipStream_t s) {
     NVQ_REQUIRE((size_t)d.n * d.h * d.w * d.in_ld < ((size_t)1 << 32),
                 "conv_forward(bf16, 32x32x16): input tensor of %d x %d x %d x %d elements exceeds the 32-bit offsets of the kernels",
@@ -608,10 +623,11 @@ int conv_forward_m32(const nvq_conv_desc& d, int variant, int dbg, hipStream_t s
     const int tilesX = (d.w + TW - 1) / TW, tilesY = (d.h + 15) / 16;
     const int nkc = (d.cin + KCB - 1) / KCB;
     const dim3 grid((unsigned)((long)tilesX * tilesY * d.n));
-    if (variant == 64) {                                      // 64 output channels per workgroup, 8 x 32 tiles (the caller checks)
+    if (variant == 64 || variant == 65) {                     // 64 output channels per workgroup, 8 x 32 tiles (the caller checks)
         const int tY8 = (d.h + 7) / 8;
-        hipLaunchKernelGGL(conv_m32w_kernel, dim3((unsigned)((long)tilesX * tY8 * d.n), (d.cout_store + 63) / 64), dim3(256), 0, s, d,
-                           tilesX, tY8, nkc, dbg);
+        const dim3 g8((unsigned)((long)tilesX * tY8 * d.n), (d.cout_store + 63) / 64);
+        if (variant == 64) hipLaunchKernelGGL((conv_m32w_kernel<4, 2>), g8, dim3(256), 0, s, d, tilesX, tY8, nkc, dbg);
+        else hipLaunchKernelGGL((conv_m32w_kernel<8, 1>), g8, dim3(512), 0, s, d, tilesX, tY8, nkc, dbg);
     } else if (variant == 2)
         hipLaunchKernelGGL((conv_m32_kernel<2, 8, false>), grid, dim3(512), 0, s, d, tilesX, tilesY, nkc, dbg);
     else

@@ -114,7 +114,8 @@ typedef struct nvq_conv_desc {
      * 32-channel halves per workgroup for cout >= 64); for cout <= 32 also
      * 16 = the 16x32-tile kernel on v_mfma_f32_16x16x32_bf16, 162 / 164 = the same tile on v_mfma_f32_32x32x16_bf16 with two /
      * four tile rows per wave (automatic: 162 up to 128 input channels, 16 above); for cout >= 64 (a multiple of 64 stored channels,
-     * bf16 output) 264 = a wave of 2 rows x 64 channels on v_mfma_f32_32x32x16_bf16 (measured slower, never automatic).  Lets a caller A/B the forms without any
+     * bf16 output) 264 / 265 = v_mfma_f32_32x32x16_bf16 forms (a wave of 2 rows x 64 channels / eight channel-split waves;
+     * measured slower or equal, never automatic).  Lets a caller A/B the forms without any
      * library state. */
     int tile_rows;
     /* words per pixel of `bits` (0 or 1: one word, cout <= 32) */

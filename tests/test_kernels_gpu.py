@@ -1482,8 +1482,8 @@ def test_conv_bf16_one_bit_relu_masks_of_wide_layers(K, cin, cout, N, H, W):
 
 @pytest.mark.parametrize("cin,cout,N,H,W", [(96, 128, 2, 19, 37), (128, 64, 1, 16, 64), (224, 64, 1, 9, 33), (64, 192, 2, 8, 40)])
 def test_conv_bf16_wide_layers_on_32x32x16_mfma(K, cin, cout, N, H, W):
-    """tile_rows = 264: the cout >= 64 3x3 conv with a wave = 2 rows x 32 pixels x 64 channels on v_mfma_f32_32x32x16_bf16
-    (conv_m32w_kernel) against the shipped channel-split kernel and the fp32 conv of the bf16-rounded operands: bias + ReLU with
+    """tile_rows = 264 / 265: the cout >= 64 3x3 conv on v_mfma_f32_32x32x16_bf16 with a wave = 2 rows x 32 pixels x 64 channels /
+    as eight channel-split waves (conv_m32w_kernel) against the shipped channel-split kernel and the fp32 conv of the bf16-rounded operands: bias + ReLU with
     one-bit masks written (cout / 32 words per pixel), a bf16 residual, masks read, centre-tap-only leading chunks; partial
     tiles in both directions, one and several 64-channel slabs."""
     nw = cout // 32
@@ -1494,7 +1494,7 @@ def test_conv_bf16_wide_layers_on_32x32x16_mfma(K, cin, cout, N, H, W):
     res = to_nhwc_bf16(bf(rnd(N, cout, H, W, seed=9)))
     ref = F.relu(F.conv2d(xf, bf(w), b, padding=1))
     outs = {}
-    for rows in (0, 264):
+    for rows in (0, 264, 265):
         y = torch.zeros(N, H, W, cout, device="cuda", dtype=torch.bfloat16)
         bits = torch.zeros(N, H, W, nw, dtype=torch.int32, device="cuda")
         K.conv_forward(K.Sl(x), wp, b.cuda(), K.Sl(y), 3, relu=True, math=K.MATH_BF16, bits=bits, bits_mode=1, tile_rows=rows)
@@ -1508,16 +1508,18 @@ def test_conv_bf16_wide_layers_on_32x32x16_mfma(K, cin, cout, N, H, W):
         K.conv_forward(K.Sl(x), wp, None, K.Sl(y3), 3, math=K.MATH_BF16, bits=bits, bits_mode=2, tile_rows=rows)
         assert torch.equal(y3 != 0, (y3 != 0) & (y > 0))    # nothing passes where the mask bit is clear
         outs[rows] = (y, y2, y3)
-    for a, c in zip(outs[0], outs[264]):
-        assert rel(a.float(), c.float()) < 5e-3
+    for v in (264, 265):
+        for a, c in zip(outs[0], outs[v]):
+            assert rel(a.float(), c.float()) < 5e-3
     if cin >= 96:                                            # centre-tap-only leading chunks (the blocks' input-gradient conv)
         wc = w.clone()
         wc[:, :64, [0, 0, 0, 1, 1, 2, 2, 2], [0, 1, 2, 0, 2, 0, 1, 2]] = 0
         wcp = K.conv_pack(wc.cuda(), False, cin, math=K.MATH_BF16)
         ya, yb = torch.zeros(N, H, W, cout, device="cuda", dtype=torch.bfloat16), torch.zeros(N, H, W, cout, device="cuda", dtype=torch.bfloat16)
-        K.conv_forward(K.Sl(x), wcp, None, K.Sl(ya), 3, math=K.MATH_BF16, center_cin=64, tile_rows=264)
-        K.conv_forward(K.Sl(x), wcp, None, K.Sl(yb), 3, math=K.MATH_BF16, tile_rows=264)
-        assert torch.equal(ya, yb) and rel(from_nhwc(ya.float()), F.conv2d(xf, bf(wc), None, padding=1)) < 5e-3
+        for v in (264, 265):
+            K.conv_forward(K.Sl(x), wcp, None, K.Sl(ya), 3, math=K.MATH_BF16, center_cin=64, tile_rows=v)
+            K.conv_forward(K.Sl(x), wcp, None, K.Sl(yb), 3, math=K.MATH_BF16, tile_rows=v)
+            assert torch.equal(ya, yb) and rel(from_nhwc(ya.float()), F.conv2d(xf, bf(wc), None, padding=1)) < 5e-3
 
 
 def test_dwconv_bf16_with_fused_batchnorm_input(K):
