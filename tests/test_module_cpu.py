@@ -125,3 +125,34 @@ def test_frame_recovery_and_default_engine_state_dict_and_default_init_equal_the
         assert len(list(m.parameters())) == 117
         with pytest.raises(RuntimeError):
             m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 2, 3, 64, 64))      # CPU tensors: no fallback
+
+
+def test_cached_parameter_slots_follow_the_module():
+    """BucketedNet._slots (the per-step replacement of named_parameters / named_buffers walks): same names, same order, the same
+    tensor objects as the module tree - also after a parameter or buffer has been REPLACED (attribute assignment,
+    load_state_dict(assign=True)), after .to(dtype) and in a deepcopy (whose slots must point into the copy)."""
+    from nerve_cl.models import FrameRecoveryNet, LightweightSuperResolution
+    for m in (SuperResolutionNet(num_features=32, num_residual_blocks=2), LightweightSuperResolution(scale_factor=2), FrameRecoveryNet()):
+        def same(net):
+            got, want = net._named_params(), list(net.named_parameters())
+            assert [n for n, _ in got] == [n for n, _ in want] and all(a is b for (_, a), (_, b) in zip(got, want))
+            td = net._tensor_dict()
+            assert list(td) == [n for n, _ in want] + [n for n, _ in net.named_buffers()]
+            for n, b in net.named_buffers():
+                assert td[n] is b
+            for n, p in want:
+                assert td[n].data_ptr() == p.data_ptr()
+        same(m)
+        name, old = next(iter(m.named_parameters()))
+        owner = m.get_submodule(name.rpartition(".")[0])
+        setattr(owner, name.rpartition(".")[2], torch.nn.Parameter(torch.zeros_like(old)))     # a replaced Parameter object
+        same(m)
+        assert m._named_params()[0][1] is not old
+        sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, assign=True)                                                   # every tensor replaced
+        same(m)
+        m.double()
+        same(m)
+        c = copy.deepcopy(m)
+        same(c)
+        assert all(a is not b for (_, a), (_, b) in zip(c._named_params(), m._named_params()))
